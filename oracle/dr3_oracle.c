@@ -1,0 +1,753 @@
+/*
+ * dr3_oracle.c -- CPU restatement of the 3DR dense hot path.  TEST INFRASTRUCTURE ONLY
+ * (see dr3_oracle.h for the scope statement and the "PARITY UNPINNED" notice).
+ *
+ * Build: gcc -O2 -std=c99 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC
+ * -ffp-contract=off matters: OpenCV's baseline x86-64 build (SSE3) issues no FMA, and the
+ * HIP kernels are compiled the same way so float results can be compared bit for bit.
+ */
+#include "dr3_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
+static inline int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else       p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+static inline int cv_round_f(float v)  { return (int)lrintf(v); }  /* cvRound(float): half-to-even */
+static inline int cv_round_d(double v) { return (int)lrint(v); }   /* cvRound(double) / saturate_cast<int>(double) */
+static inline int cv_floor_f(float v)  { return (int)floorf(v); }
+
+static inline short sat_s16(int v)
+{
+    return (short)(v < SHRT_MIN ? SHRT_MIN : v > SHRT_MAX ? SHRT_MAX : v);
+}
+
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+static void set_threads(int n_threads)
+{
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A-1  pyramid                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv::buildOpticalFlowPyramid's early stop: after producing level l the
+ * next size is ((w+1)/2,(h+1)/2); if that is <= winSize in either dimension, level l is the last. */
+int dr3o_lk_effective_max_level(int w, int h, int win_w, int win_h, int max_level)
+{
+    int level;
+    for (level = 0; level <= max_level; ++level) {
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        if (w <= win_w || h <= win_h) return level;
+    }
+    return max_level;
+}
+
+/* cv::pyrDown for CV_8U (pyramids.cpp, PyrDownInvoker<FixPtCast<uchar,8>>): separable
+ * [1 4 6 4 1], integer row sums, (v+128)>>8, REFLECT_101 on the source level itself. */
+void dr3o_pyr_down_u8(const uint8_t* src, int sw, int sh, int sstride,
+                      uint8_t* dst, int dstride)
+{
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    int y;
+#pragma omp parallel for schedule(static)
+    for (y = 0; y < dh; ++y) {
+        int x, k;
+        for (x = 0; x < dw; ++x) {
+            int rows[5];
+            for (k = 0; k < 5; ++k) {
+                const uint8_t* s = src + (size_t)reflect101(2 * y + k - 2, sh) * sstride;
+                const int x0 = reflect101(2 * x - 2, sw), x1 = reflect101(2 * x - 1, sw);
+                const int x2 = reflect101(2 * x, sw),     x3 = reflect101(2 * x + 1, sw);
+                const int x4 = reflect101(2 * x + 2, sw);
+                rows[k] = s[x2] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+            }
+            {
+                const int v = rows[2] * 6 + (rows[1] + rows[3]) * 4 + rows[0] + rows[4];
+                dst[(size_t)y * dstride + x] = (uint8_t)((v + 128) >> 8);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A-2  Scharr derivatives                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* calcSharrDeriv (lkpyramid.cpp): vertical [3 10 3] / [-1 0 1] into two temp rows, replicate the
+ * REFLECT_101 column, then horizontal [-1 0 1] / [3 10 3].  Un-normalised (x32). */
+void dr3o_scharr_s16(const uint8_t* src, int w, int h, int stride,
+                     int16_t* dst, int dstride)
+{
+    int y;
+#pragma omp parallel for schedule(static)
+    for (y = 0; y < h; ++y) {
+        const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : (h > 1 ? 1 : 0)) * stride;
+        const uint8_t* r1 = src + (size_t)y * stride;
+        const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0)) * stride;
+        int16_t* d = dst + (size_t)y * dstride;
+        int x;
+        for (x = 0; x < w; ++x) {
+            const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0);
+            const int xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+            /* trow0 = smoothed-in-y, trow1 = differentiated-in-y */
+            const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10;
+            const int t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
+            const int t1m = r2[xm] - r0[xm];
+            const int t1c = r2[x] - r0[x];
+            const int t1p = r2[xp] - r0[xp];
+            d[2 * x]     = (int16_t)(t0p - t0m);
+            d[2 * x + 1] = (int16_t)((t1p + t1m) * 3 + t1c * 10);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A-3  Lucas-Kanade tracker                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    const uint8_t* img; int w, h, stride;         /* un-padded level */
+} lvl_img;
+typedef struct {
+    const int16_t* d; int w, h, stride;           /* interleaved (Ix,Iy), stride in int16 */
+} lvl_deriv;
+
+/* value of the REFLECT_101-padded level at virtual (x,y); OpenCV pads by winSize, and the
+ * bounds tests keep every read inside that pad, so index reflection is equivalent. */
+static inline int img_at(const lvl_img* L, int x, int y)
+{
+    return L->img[(size_t)reflect101(y, L->h) * L->stride + reflect101(x, L->w)];
+}
+/* derivative image is padded with constant 0 */
+static inline int der_at(const lvl_deriv* D, int x, int y, int c)
+{
+    if (x < 0 || y < 0 || x >= D->w || y >= D->h) return 0;
+    return D->d[(size_t)y * D->stride + 2 * x + c];
+}
+
+/* Window-sum accumulator that can emulate either summation order. */
+typedef struct {
+    int   order;
+    int   win_w, rpr;             /* runs per row for WAVE64 */
+    float lane[3][64];            /* up to three simultaneous sums */
+    float acc[3];
+} wsum;
+
+static void wsum_init(wsum* s, int order, int win_w)
+{
+    s->order = order; s->win_w = win_w; s->rpr = (win_w + 3) / 4;
+    memset(s->lane, 0, sizeof(s->lane));
+    s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
+}
+/* WAVE64 order: lane-item q = ty*rpr + (tx/4); pass = q/64, lane = q%64.  Because the caller
+ * walks taps in raster order, for a fixed lane the sequence (pass asc, k asc) is preserved. */
+static inline void wsum_add(wsum* s, int which, int tx, int ty, float v)
+{
+    if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += v; return; }
+    {
+        const int q = ty * s->rpr + (tx >> 2);
+        s->lane[which][q & 63] += v;
+    }
+}
+static float wsum_get(wsum* s, int which)
+{
+    if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
+    {
+        float a[64], b[64];
+        int off, l;
+        memcpy(a, s->lane[which], sizeof(a));
+        for (off = 1; off < 64; off <<= 1) {          /* xor butterfly, stages 1,2,4,8,16,32 */
+            for (l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ off];
+            memcpy(a, b, sizeof(a));
+        }
+        return a[0];
+    }
+}
+
+/* NOTE on WAVE64 and pass ordering: a lane that owns items in several passes adds them in pass
+ * order (pass 0's four taps, then pass 1's...).  Raster order visits (ty asc, tx asc); item q is
+ * monotone in (ty, tx>>2), so for one lane q, q+64, q+128 ... are visited in ascending order and
+ * the taps of one item in ascending k.  Hence wsum_add above reproduces the kernel's order. */
+
+static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* dI,
+                           int max_level, const float* prev_pt, float* next_pt,
+                           uint8_t* status, float* err,
+                           int win_w, int win_h, int max_count, double epsilon,
+                           int flags, double min_eig_threshold, int order,
+                           int16_t* Ibuf, int16_t* dIbuf, int* iters)
+{
+    const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    float nx = next_pt[0], ny = next_pt[1];   /* nextPts[ptidx] */
+    int level;
+
+    *status = 1;
+    *err = 0.f;
+
+    for (level = max_level; level >= 0; --level) {
+        const lvl_img* Il = &I[level];
+        const lvl_img* Jl = &J[level];
+        const lvl_deriv* Dl = &dI[level];
+        const float scale = (float)(1. / (1 << level));
+        float px = prev_pt[0] * scale, py = prev_pt[1] * scale;
+        float cx, cy;                 /* nextPt */
+        int ipx, ipy, x, y, j;
+        float a, b, A11, A12, A22, D, minEig;
+        int iw00, iw01, iw10, iw11;
+        wsum S;
+        float pdx = 0.f, pdy = 0.f;   /* prevDelta */
+
+        if (iters) iters[level] = 0;
+
+        if (level == max_level) {
+            if (flags & DR3O_LK_USE_INITIAL_FLOW) { cx = nx * scale; cy = ny * scale; }
+            else { cx = px; cy = py; }
+        } else {
+            cx = nx * 2.f; cy = ny * 2.f;
+        }
+        nx = cx; ny = cy;
+
+        px -= half_x; py -= half_y;
+        ipx = cv_floor_f(px); ipy = cv_floor_f(py);
+
+        if (ipx < -win_w || ipx >= Dl->w || ipy < -win_h || ipy >= Dl->h) {
+            if (level == 0) { *status = 0; *err = 0.f; }
+            continue;
+        }
+
+        a = px - ipx; b = py - ipy;
+        iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+        iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+        iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+        iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+        wsum_init(&S, order, win_w);
+        for (y = 0; y < win_h; ++y) {
+            for (x = 0; x < win_w; ++x) {
+                const int X = ipx + x, Y = ipy + y;
+                const int ival = DESCALE(img_at(Il, X, Y) * iw00 + img_at(Il, X + 1, Y) * iw01 +
+                                         img_at(Il, X, Y + 1) * iw10 + img_at(Il, X + 1, Y + 1) * iw11,
+                                         W_BITS - 5);
+                const int ixval = DESCALE(der_at(Dl, X, Y, 0) * iw00 + der_at(Dl, X + 1, Y, 0) * iw01 +
+                                          der_at(Dl, X, Y + 1, 0) * iw10 + der_at(Dl, X + 1, Y + 1, 0) * iw11,
+                                          W_BITS);
+                const int iyval = DESCALE(der_at(Dl, X, Y, 1) * iw00 + der_at(Dl, X + 1, Y, 1) * iw01 +
+                                          der_at(Dl, X, Y + 1, 1) * iw10 + der_at(Dl, X + 1, Y + 1, 1) * iw11,
+                                          W_BITS);
+                Ibuf[y * win_w + x] = (int16_t)ival;
+                dIbuf[2 * (y * win_w + x)]     = (int16_t)ixval;
+                dIbuf[2 * (y * win_w + x) + 1] = (int16_t)iyval;
+                wsum_add(&S, 0, x, y, (float)(ixval * ixval));
+                wsum_add(&S, 1, x, y, (float)(ixval * iyval));
+                wsum_add(&S, 2, x, y, (float)(iyval * iyval));
+            }
+        }
+        A11 = wsum_get(&S, 0) * FLT_SCALE;
+        A12 = wsum_get(&S, 1) * FLT_SCALE;
+        A22 = wsum_get(&S, 2) * FLT_SCALE;
+
+        D = A11 * A22 - A12 * A12;
+        minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                 (float)(2 * win_w * win_h);
+
+        if (flags & DR3O_LK_GET_MIN_EIGENVALS) *err = minEig;
+
+        if ((double)minEig < min_eig_threshold || D < FLT_EPSILON) {
+            if (level == 0) *status = 0;
+            continue;
+        }
+
+        D = 1.f / D;
+        cx -= half_x; cy -= half_y;
+
+        for (j = 0; j < max_count; ++j) {
+            const int inx = cv_floor_f(cx), iny = cv_floor_f(cy);
+            float b1, b2, dx, dy;
+
+            if (inx < -win_w || inx >= Jl->w || iny < -win_h || iny >= Jl->h) {
+                if (level == 0) *status = 0;
+                break;
+            }
+            if (iters) iters[level] = j + 1;
+
+            a = cx - inx; b = cy - iny;
+            iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+            wsum_init(&S, order, win_w);
+            for (y = 0; y < win_h; ++y) {
+                for (x = 0; x < win_w; ++x) {
+                    const int X = inx + x, Y = iny + y;
+                    const int diff = DESCALE(img_at(Jl, X, Y) * iw00 + img_at(Jl, X + 1, Y) * iw01 +
+                                             img_at(Jl, X, Y + 1) * iw10 + img_at(Jl, X + 1, Y + 1) * iw11,
+                                             W_BITS - 5) - Ibuf[y * win_w + x];
+                    wsum_add(&S, 0, x, y, (float)(diff * dIbuf[2 * (y * win_w + x)]));
+                    wsum_add(&S, 1, x, y, (float)(diff * dIbuf[2 * (y * win_w + x) + 1]));
+                }
+            }
+            b1 = wsum_get(&S, 0) * FLT_SCALE;
+            b2 = wsum_get(&S, 1) * FLT_SCALE;
+
+            dx = (float)((A12 * b2 - A22 * b1) * D);
+            dy = (float)((A12 * b1 - A11 * b2) * D);
+
+            cx += dx; cy += dy;
+            nx = cx + half_x; ny = cy + half_y;
+
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        if (*status && level == 0 && !(flags & DR3O_LK_GET_MIN_EIGENVALS)) {
+            const float fx = nx - half_x, fy = ny - half_y;
+            const int inx = cv_floor_f(fx), iny = cv_floor_f(fy);
+            float errval;
+
+            if (inx < -win_w || inx >= Jl->w || iny < -win_h || iny >= Jl->h) {
+                *status = 0;
+                continue;
+            }
+            a = fx - inx; b = fy - iny;
+            iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+            wsum_init(&S, order, win_w);
+            for (y = 0; y < win_h; ++y) {
+                for (x = 0; x < win_w; ++x) {
+                    const int X = inx + x, Y = iny + y;
+                    const int diff = DESCALE(img_at(Jl, X, Y) * iw00 + img_at(Jl, X + 1, Y) * iw01 +
+                                             img_at(Jl, X, Y + 1) * iw10 + img_at(Jl, X + 1, Y + 1) * iw11,
+                                             W_BITS - 5) - Ibuf[y * win_w + x];
+                    wsum_add(&S, 0, x, y, fabsf((float)diff));
+                }
+            }
+            errval = wsum_get(&S, 0);
+            *err = errval * 1.f / (float)(32 * win_w * win_h);
+        }
+    }
+    next_pt[0] = nx; next_pt[1] = ny;
+}
+
+int dr3o_lk_track_ex(const uint8_t* prev, const uint8_t* next, int w, int h,
+                     int prev_stride, int next_stride,
+                     const float* prev_xy, float* next_xy, int n,
+                     uint8_t* status, float* err, const dr3o_lk_params* p,
+                     int order, int n_threads, int* iters)
+{
+    enum { MAXL = 16 };
+    lvl_img I[MAXL], J[MAXL];
+    lvl_deriv dI[MAXL];
+    uint8_t* ibuf[MAXL]; uint8_t* jbuf[MAXL]; int16_t* dbuf[MAXL];
+    int max_level, l, i, max_count;
+    double epsilon;
+
+    if (!prev || !next || !p || w <= 0 || h <= 0 || n < 0) return -1;
+    if (p->max_level < 0 || p->max_level >= MAXL || p->win_w <= 2 || p->win_h <= 2) return -2;
+    set_threads(n_threads);
+
+    max_level = dr3o_lk_effective_max_level(w, h, p->win_w, p->win_h, p->max_level);
+
+    /* TermCriteria clamping (SparsePyrLKOpticalFlowImpl::calc) */
+    max_count = (p->crit_type & 1) ? (p->max_iters < 0 ? 0 : p->max_iters > 100 ? 100 : p->max_iters) : 30;
+    epsilon   = (p->crit_type & 2) ? (p->eps < 0. ? 0. : p->eps > 10. ? 10. : p->eps) : 0.01;
+    epsilon *= epsilon;
+
+    memset(ibuf, 0, sizeof(ibuf)); memset(jbuf, 0, sizeof(jbuf)); memset(dbuf, 0, sizeof(dbuf));
+    I[0].img = prev; I[0].w = w; I[0].h = h; I[0].stride = prev_stride;
+    J[0].img = next; J[0].w = w; J[0].h = h; J[0].stride = next_stride;
+    for (l = 1; l <= max_level; ++l) {
+        const int lw = (I[l - 1].w + 1) / 2, lh = (I[l - 1].h + 1) / 2;
+        ibuf[l] = (uint8_t*)malloc((size_t)lw * lh);
+        jbuf[l] = (uint8_t*)malloc((size_t)lw * lh);
+        dr3o_pyr_down_u8(I[l - 1].img, I[l - 1].w, I[l - 1].h, I[l - 1].stride, ibuf[l], lw);
+        dr3o_pyr_down_u8(J[l - 1].img, J[l - 1].w, J[l - 1].h, J[l - 1].stride, jbuf[l], lw);
+        I[l].img = ibuf[l]; I[l].w = lw; I[l].h = lh; I[l].stride = lw;
+        J[l].img = jbuf[l]; J[l].w = lw; J[l].h = lh; J[l].stride = lw;
+    }
+    for (l = 0; l <= max_level; ++l) {
+        dbuf[l] = (int16_t*)malloc((size_t)I[l].w * I[l].h * 2 * sizeof(int16_t));
+        dr3o_scharr_s16(I[l].img, I[l].w, I[l].h, I[l].stride, dbuf[l], 2 * I[l].w);
+        dI[l].d = dbuf[l]; dI[l].w = I[l].w; dI[l].h = I[l].h; dI[l].stride = 2 * I[l].w;
+    }
+
+#pragma omp parallel
+    {
+        int16_t* Ibuf  = (int16_t*)malloc((size_t)p->win_w * p->win_h * sizeof(int16_t));
+        int16_t* dIbuf = (int16_t*)malloc((size_t)p->win_w * p->win_h * 2 * sizeof(int16_t));
+#pragma omp for schedule(dynamic, 16)
+        for (i = 0; i < n; ++i) {
+            lk_track_point(I, J, dI, max_level, prev_xy + 2 * i, next_xy + 2 * i,
+                           status + i, err + i, p->win_w, p->win_h, max_count, epsilon,
+                           p->flags, p->min_eig_threshold, order, Ibuf, dIbuf,
+                           iters ? iters + (size_t)i * (max_level + 1) : NULL);
+        }
+        free(Ibuf); free(dIbuf);
+    }
+
+    for (l = 0; l <= max_level; ++l) { free(ibuf[l]); free(jbuf[l]); free(dbuf[l]); }
+    return max_level;
+}
+
+int dr3o_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h,
+                  int prev_stride, int next_stride,
+                  const float* prev_xy, float* next_xy, int n,
+                  uint8_t* status, float* err, const dr3o_lk_params* p,
+                  int order, int n_threads)
+{
+    return dr3o_lk_track_ex(prev, next, w, h, prev_stride, next_stride, prev_xy, next_xy, n,
+                            status, err, p, order, n_threads, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* reference in-repo code: half-sample pyramid, Shi-Tomasi                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline uint8_t half_trunc(int a, int b, int c, int d) { return (uint8_t)((a + b + c + d) / 4); }
+/* _mm_avg_epu8(top,bottom) then _mm_avg_epu16(even,odd): src/utils.cpp:337,340 */
+static inline uint8_t half_sse2(int a, int b, int c, int d)
+{
+    const int v0 = (a + c + 1) >> 1, v1 = (b + d + 1) >> 1;
+    return (uint8_t)((v0 + v1 + 1) >> 1);
+}
+
+void dr3o_halfsample_u8(const uint8_t* src, int w, int h, int stride,
+                        uint8_t* dst, int dstride, int mode)
+{
+    const int ow = w / 2, oh = h / 2;
+    int y, x;
+    if (mode == DR3O_HALF_REF_X86)
+        mode = (w % 16 == 0) ? DR3O_HALF_SSE2 : DR3O_HALF_REF_SCALAR;
+
+    if (mode == DR3O_HALF_REF_SCALAR) {
+        /* src/utils.cpp:402-418: `top` advances by 2 per output pixel and by `stride` per output
+         * row, i.e. 2*ow + stride per row; for odd w that is 2*stride-1 (sheared sampling). */
+        const size_t total = (size_t)stride * h;
+        for (y = 0; y < oh; ++y) {
+            const size_t row_off = (size_t)y * (2 * (size_t)ow + stride);
+            for (x = 0; x < ow; ++x) {
+                const size_t t = row_off + 2 * (size_t)x, bt = t + stride;
+                const int a = t < total ? src[t] : 0,       b = t + 1 < total ? src[t + 1] : 0;
+                const int c = bt < total ? src[bt] : 0,     d = bt + 1 < total ? src[bt + 1] : 0;
+                dst[(size_t)y * dstride + x] = half_trunc(a, b, c, d);
+            }
+        }
+        return;
+    }
+    for (y = 0; y < oh; ++y) {
+        const uint8_t* t = src + (size_t)(2 * y) * stride;
+        const uint8_t* bt = t + stride;
+        for (x = 0; x < ow; ++x) {
+            const int a = t[2 * x], b = t[2 * x + 1], c = bt[2 * x], d = bt[2 * x + 1];
+            dst[(size_t)y * dstride + x] = (mode == DR3O_HALF_SSE2) ? half_sse2(a, b, c, d)
+                                                                    : half_trunc(a, b, c, d);
+        }
+    }
+}
+
+/* src/utils.cpp:282-321.  Unqualified sqrt() on a float inside namespace utils: resolves to
+ * ::sqrt(double) (no `using namespace std` in that TU) -- restated so; flagged unpinned. */
+float dr3o_shi_tomasi_score(const uint8_t* img, int w, int h, int stride, int u, int v)
+{
+    float dXX = 0.f, dYY = 0.f, dXY = 0.f;
+    const int halfbox = 4, box = 8, area = 64;
+    const int x_min = u - halfbox, x_max = u + halfbox, y_min = v - halfbox, y_max = v + halfbox;
+    int x, y;
+    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.f;
+    for (y = y_min; y < y_max; ++y) {
+        for (x = 0; x < box; ++x) {
+            const float dx = (float)(img[(size_t)y * stride + x_min + 1 + x] - img[(size_t)y * stride + x_min - 1 + x]);
+            const float dy = (float)(img[(size_t)(y + 1) * stride + x_min + x] - img[(size_t)(y - 1) * stride + x_min + x]);
+            dXX += dx * dx; dYY += dy * dy; dXY += dx * dy;
+        }
+    }
+    dXX = (float)(dXX / (2.0 * area));
+    dYY = (float)(dYY / (2.0 * area));
+    dXY = (float)(dXY / (2.0 * area));
+    return (float)(0.5 * (dXX + dYY - sqrt((double)((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)))));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A-4 / A-5  warpPerspective, remap                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+int dr3o_invert3x3(const double S[9], double T[9])
+{
+    /* cv::invert, n == 3, CV_64F (matrix_decomp / lapack.cpp closed form) */
+    const double d0 = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+                      S[2] * (S[3] * S[7] - S[4] * S[6]);
+    double d, t[9];
+    if (d0 == 0.) { memset(T, 0, 9 * sizeof(double)); return 0; }
+    d = 1. / d0;
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    memcpy(T, t, sizeof(t));
+    return 1;
+}
+
+static int type_channels(int type)
+{
+    switch (type) {
+    case DR3O_8UC1: return 1; case DR3O_8UC3: return 3; case DR3O_8UC4: return 4;
+    case DR3O_32FC4: return 4; case DR3O_32FC1: return 1; default: return 0;
+    }
+}
+static int type_is_float(int type) { return type == DR3O_32FC4 || type == DR3O_32FC1; }
+
+/* fixed-point bilinear table entry for fraction (fx,fy) in 1/32 px -- initInterTab2D(INTER_LINEAR,
+ * fixpt) in imgwarp.cpp.  Entry (0,0) saturates 32768 -> 32767 in `short`; OpenCV's sum-repair loop
+ * then adds the missing 1 to w11.  Neither changes any 8-bit result; kept for fidelity. */
+static inline void bilinear_w_8u(int fx, int fy, int w[4])
+{
+    w[0] = (32 - fx) * (32 - fy) * 32; w[1] = fx * (32 - fy) * 32;
+    w[2] = (32 - fx) * fy * 32;        w[3] = fx * fy * 32;
+    if (fx == 0 && fy == 0) { w[0] = 32767; w[3] = 1; }
+}
+static inline void bilinear_w_32f(int fx, int fy, float w[4])
+{
+    const float x1 = fx * (1.f / 32), x0 = 1.f - x1, y1 = fy * (1.f / 32), y0 = 1.f - y1;
+    w[0] = y0 * x0; w[1] = y0 * x1; w[2] = y1 * x0; w[3] = y1 * x1;
+}
+
+/* remapBilinear core for one destination pixel: (sx,sy) integer source, (fx,fy) 5-bit fraction,
+ * BORDER_CONSTANT 0. */
+static inline void sample_px(const uint8_t* src, int sw, int sh, int sstride, int type, int cn,
+                             int sx, int sy, int fx, int fy, uint8_t* dpx)
+{
+    const int in00 = (sx >= 0 && sy >= 0 && sx < sw && sy < sh);
+    const int in01 = (sx + 1 >= 0 && sy >= 0 && sx + 1 < sw && sy < sh);
+    const int in10 = (sx >= 0 && sy + 1 >= 0 && sx < sw && sy + 1 < sh);
+    const int in11 = (sx + 1 >= 0 && sy + 1 >= 0 && sx + 1 < sw && sy + 1 < sh);
+    int k;
+    if (!type_is_float(type)) {
+        int w[4];
+        bilinear_w_8u(fx, fy, w);
+        for (k = 0; k < cn; ++k) {
+            const int v0 = in00 ? src[(size_t)sy * sstride + sx * cn + k] : 0;
+            const int v1 = in01 ? src[(size_t)sy * sstride + (sx + 1) * cn + k] : 0;
+            const int v2 = in10 ? src[(size_t)(sy + 1) * sstride + sx * cn + k] : 0;
+            const int v3 = in11 ? src[(size_t)(sy + 1) * sstride + (sx + 1) * cn + k] : 0;
+            const int v = (v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + (1 << 14)) >> 15;
+            dpx[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    } else {
+        float w[4];
+        float* d = (float*)dpx;
+        bilinear_w_32f(fx, fy, w);
+        for (k = 0; k < cn; ++k) {
+            const float v0 = in00 ? *(const float*)(src + (size_t)sy * sstride + ((size_t)sx * cn + k) * 4) : 0.f;
+            const float v1 = in01 ? *(const float*)(src + (size_t)sy * sstride + ((size_t)(sx + 1) * cn + k) * 4) : 0.f;
+            const float v2 = in10 ? *(const float*)(src + (size_t)(sy + 1) * sstride + ((size_t)sx * cn + k) * 4) : 0.f;
+            const float v3 = in11 ? *(const float*)(src + (size_t)(sy + 1) * sstride + ((size_t)(sx + 1) * cn + k) * 4) : 0.f;
+            d[k] = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+        }
+    }
+}
+
+int dr3o_warp_perspective(const void* src_, int sw, int sh, int sstride, int type,
+                          void* dst_, int dw, int dh, int dstride,
+                          const float Mf[9], int flags, int n_threads)
+{
+    const uint8_t* src = (const uint8_t*)src_;
+    uint8_t* dst = (uint8_t*)dst_;
+    const int cn = type_channels(type);
+    const int esz = cn * (type_is_float(type) ? 4 : 1);
+    double M[9];
+    int i, y, bh0, bw0;
+    if (!src || !dst || cn == 0 || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return -1;
+    set_threads(n_threads);
+    for (i = 0; i < 9; ++i) M[i] = (double)Mf[i];                 /* M0.convertTo(matM, CV_64F) */
+    if (!(flags & DR3O_WARP_INVERSE_MAP)) dr3o_invert3x3(M, M);   /* invert(matM, matM)          */
+
+    /* WarpPerspectiveInvoker block geometry: only the x0 + x1 split influences f64 rounding */
+    bh0 = dh < 16 ? dh : 16;
+    bw0 = (1024 / bh0) < dw ? (1024 / bh0) : dw;
+
+#pragma omp parallel for schedule(static)
+    for (y = 0; y < dh; ++y) {
+        int x;
+        for (x = 0; x < dw; ++x) {
+            const int x0 = (x / bw0) * bw0, x1 = x - x0;
+            const double X0 = M[0] * x0 + M[1] * y + M[2];
+            const double Y0 = M[3] * x0 + M[4] * y + M[5];
+            const double W0 = M[6] * x0 + M[7] * y + M[8];
+            double W = W0 + M[6] * x1;
+            double fX, fY;
+            int X, Y;
+            W = W ? 32. / W : 0;
+            fX = (X0 + M[0] * x1) * W; fY = (Y0 + M[3] * x1) * W;
+            fX = fX < (double)INT_MIN ? (double)INT_MIN : fX > (double)INT_MAX ? (double)INT_MAX : fX;
+            fY = fY < (double)INT_MIN ? (double)INT_MIN : fY > (double)INT_MAX ? (double)INT_MAX : fY;
+            X = cv_round_d(fX); Y = cv_round_d(fY);
+            sample_px(src, sw, sh, sstride, type, cn, sat_s16(X >> 5), sat_s16(Y >> 5), X & 31, Y & 31,
+                      dst + (size_t)y * dstride + (size_t)x * esz);
+        }
+    }
+    return 0;
+}
+
+int dr3o_remap_bilinear(const void* src_, int sw, int sh, int sstride, int type,
+                        void* dst_, int dw, int dh, int dstride,
+                        const float* mapx, const float* mapy, int map_stride,
+                        int n_threads)
+{
+    const uint8_t* src = (const uint8_t*)src_;
+    uint8_t* dst = (uint8_t*)dst_;
+    const int cn = type_channels(type);
+    const int esz = cn * (type_is_float(type) ? 4 : 1);
+    int y;
+    if (!src || !dst || !mapx || !mapy || cn == 0) return -1;
+    set_threads(n_threads);
+#pragma omp parallel for schedule(static)
+    for (y = 0; y < dh; ++y) {
+        int x;
+        for (x = 0; x < dw; ++x) {
+            const int sx = cv_round_f(mapx[(size_t)y * map_stride + x] * 32.f);
+            const int sy = cv_round_f(mapy[(size_t)y * map_stride + x] * 32.f);
+            sample_px(src, sw, sh, sstride, type, cn, sat_s16(sx >> 5), sat_s16(sy >> 5), sx & 31, sy & 31,
+                      dst + (size_t)y * dstride + (size_t)x * esz);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* "next" rows: map generation, feather, normalise                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/utils.cpp:125-187.  xf = (float)((j - 0.5*w)/f) (double arithmetic, stored float, :153-156);
+ * unqualified sin/cos on float -> ::sin(double) in that TU; xhat = (float)(sin*cos) (:170-172);
+ * xhat /= zhat in float (:179-180); u = 0.5*w + xhat*f evaluated by cv::MatExpr as
+ * xhat*f + 0.5*w in float (scaleAdd), restated as float multiply-add without contraction. */
+void dr3o_spherical_map(int w, int h, float f, float* u, float* v)
+{
+    int i, j;
+    for (i = 0; i < h; ++i) {
+        for (j = 0; j < w; ++j) {
+            const float xf = (float)(((double)(float)j - 0.5 * w) / (double)f);
+            const float yf = (float)(((double)(float)i - 0.5 * h) / (double)f);
+            float xhat = (float)(sin((double)xf) * cos((double)yf));
+            float yhat = (float)sin((double)yf);
+            const float zhat = (float)(cos((double)xf) * cos((double)yf));
+            xhat /= zhat; yhat /= zhat;
+            u[(size_t)i * w + j] = (float)(0.5 * w) + xhat * f;
+            v[(size_t)i * w + j] = (float)(0.5 * h) + yhat * f;
+        }
+    }
+}
+
+/* src/utils.cpp:203-265 */
+void dr3o_cylindrical_map(int w, int h, float f, float* u, float* v)
+{
+    int i, j;
+    for (i = 0; i < h; ++i) {
+        for (j = 0; j < w; ++j) {
+            const float th = (float)(((double)(float)j - 0.5 * w) / (double)f);
+            const float hh = (float)(((double)(float)i - 0.5 * h) / (double)f);
+            float xhat = (float)sin((double)th);
+            float yhat = hh;
+            const float zhat = (float)cos((double)th);
+            xhat /= zhat; yhat /= zhat;
+            u[(size_t)i * w + j] = (float)(0.5 * w) + xhat * f;
+            v[(size_t)i * w + j] = (float)(0.5 * h) + yhat * f;
+        }
+    }
+}
+
+/* include/utils.hpp:37-46: val += h accumulation in T */
+void dr3o_linspace_f32(float a, float b, int n, float* out)
+{
+    const float hstep = (b - a) / (float)(n - 1);
+    float val = a;
+    int i;
+    for (i = 0; i < n; ++i) { out[i] = val; val += hstep; }
+}
+
+/* src/panorama.cpp:194-212.  Scales BGR by the ramp, sets alpha to the ramp, drops pixels whose
+ * scaled BGR is exactly (0,0,0), accumulates the rest into the canvas. */
+void dr3o_feather_accumulate(float* canvas, int cw, int ch, int cstride,
+                             float* warped, int wstride,
+                             int min_x, int max_x, const float* ramp)
+{
+    int i, j;
+    for (i = min_x; i != max_x; ++i) {
+        if (i < 0 || i >= cw) continue;   /* reference indexes unclamped (Appendix B-5); OOB skipped here */
+        for (j = 0; j < ch; ++j) {
+            float* wp = (float*)((uint8_t*)warped + (size_t)j * wstride) + 4 * i;
+            float* cp = (float*)((uint8_t*)canvas + (size_t)j * cstride) + 4 * i;
+            const float r = ramp[i - min_x];
+            wp[0] *= r; wp[1] *= r; wp[2] *= r;
+            wp[3] = r;
+            if (wp[0] == 0 && wp[1] == 0 && wp[2] == 0) {
+                wp[3] = 0.0f;
+            } else {
+                cp[0] += wp[0]; cp[1] += wp[1]; cp[2] += wp[2]; cp[3] += wp[3];
+            }
+        }
+    }
+}
+
+/* src/panorama.cpp:215-229: vec[c] = (int)canvas[c] / alpha  -> int cast first, float divide,
+ * then float -> uchar narrowing (cv::Vec3b element assignment = plain C++ conversion). */
+void dr3o_normalize_canvas(const float* canvas, int cw, int ch, int cstride,
+                           uint8_t* out, int ostride)
+{
+    int i, j, c;
+    for (i = 0; i < ch; ++i) {
+        const float* cp = (const float*)((const uint8_t*)canvas + (size_t)i * cstride);
+        for (j = 0; j < cw; ++j) {
+            const float alpha = cp[4 * j + 3];
+            uint8_t* o = out + (size_t)i * ostride + 3 * j;
+            o[0] = o[1] = o[2] = 0;
+            if (alpha > 0.0f) {
+                for (c = 0; c < 3; ++c) {
+                    const float q = (float)(int)cp[4 * j + c] / alpha;
+                    o[c] = (uint8_t)(int)q;   /* float->uchar: UB when out of range; restated via int */
+                }
+            }
+        }
+    }
+}

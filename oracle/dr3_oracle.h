@@ -1,0 +1,131 @@
+/*
+ * dr3_oracle.h -- CPU restatement of the 3DR dense hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle for the HIP library in 3dr_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * path never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (kvmanohar22/3DR) holds no golden vectors, no asserting
+ * tests and no fixtures for this path, and its arithmetic lives in OpenCV 3.x, an un-vendored
+ * and un-pinned system dependency (reference CMakeLists.txt:8,12) that is absent here, so the
+ * reference cannot be compiled or run.  The oracle restates the published OpenCV 3.4
+ * algorithms (modules/video/src/lkpyramid.cpp, modules/imgproc/src/pyramids.cpp,
+ * modules/imgproc/src/imgwarp.cpp) as summarised in SURVEY.md Appendix A, anchored on the
+ * reference's call sites:
+ *     cv::calcOpticalFlowPyrLK   src/initialization.cpp:608-613  (params :593-599)
+ *     cv::warpPerspective        src/stitch.cpp:73-74, src/panorama.cpp:192
+ *     cv::remap                  src/utils.cpp:191
+ * and, for in-repo code, follows the reference source line by line in behaviour:
+ *     utils::reduce_to_half / create_img_pyramid   src/utils.cpp:324-430
+ *     utils::shi_tomasi_score                      src/utils.cpp:282-321
+ * It is pinned only by analytic known-answer tests and an independent numpy restatement
+ * (tests/test_oracle_*.py).
+ */
+#ifndef DR3_ORACLE_H
+#define DR3_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pixel types (values chosen to match the C-ABI's DR3HIP_8UC1.. so tests pass one constant) */
+#define DR3O_8UC1   0
+#define DR3O_8UC3   1
+#define DR3O_32FC4  2
+#define DR3O_8UC4   3
+#define DR3O_32FC1  4
+
+#define DR3O_LK_USE_INITIAL_FLOW   4   /* cv::OPTFLOW_USE_INITIAL_FLOW */
+#define DR3O_LK_GET_MIN_EIGENVALS  8   /* cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+
+#define DR3O_WARP_INVERSE_MAP     16   /* cv::WARP_INVERSE_MAP */
+
+/* float summation order of the window sums (A11,A12,A22,b1,b2,err) */
+#define DR3O_ORDER_RASTER   0  /* OpenCV's scalar path: y outer, x inner, one f32 accumulator */
+#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order: 64 lanes x runs of 4 taps, xor butterfly */
+
+/* half-sample rounding / addressing modes (src/utils.cpp:382-419) */
+#define DR3O_HALF_TRUNC      0 /* row-aligned, (a+b+c+d)/4 truncating  (scalar :411, NEON :353-372) */
+#define DR3O_HALF_SSE2       1 /* row-aligned, avg(avg(a,c),avg(b,d)) rounding up twice (:337,:340) */
+#define DR3O_HALF_REF_SCALAR 2 /* the scalar pointer walk exactly as written (:402-418): sheared for odd width */
+#define DR3O_HALF_REF_X86    3 /* what the reference executes on x86-64: SSE2 when cols%16==0 (:387-392), else REF_SCALAR */
+
+typedef struct dr3o_lk_params {
+    int   win_w, win_h;       /* cv::Size winSize                              */
+    int   max_level;          /* requested maxLevel (effective may be lower)   */
+    int   crit_type;          /* cv::TermCriteria::type: COUNT=1, EPS=2        */
+    int   max_iters;          /* un-clamped maxCount (clamped to [0,100])      */
+    double eps;               /* un-clamped epsilon (clamped to [0,10], squared) */
+    int   flags;              /* DR3O_LK_*                                     */
+    double min_eig_threshold; /* default 1e-4                                  */
+} dr3o_lk_params;
+
+/* A-1: number of levels buildOpticalFlowPyramid keeps; returns the effective maxLevel. */
+int  dr3o_lk_effective_max_level(int w, int h, int win_w, int win_h, int max_level);
+
+/* A-1: cv::pyrDown u8, dst size ((sw+1)/2, (sh+1)/2), BORDER_REFLECT_101. */
+void dr3o_pyr_down_u8(const uint8_t* src, int sw, int sh, int sstride,
+                      uint8_t* dst, int dstride);
+
+/* A-2: calcSharrDeriv, dst interleaved (Ix,Iy) int16, dstride in int16 elements per row. */
+void dr3o_scharr_s16(const uint8_t* src, int w, int h, int stride,
+                     int16_t* dst, int dstride);
+
+/* A-3: cv::calcOpticalFlowPyrLK on single-channel u8 images.  Returns effective max level (>=0)
+ * or <0 on bad arguments.  n_threads<=0 -> OpenMP default. */
+int  dr3o_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h,
+                   int prev_stride, int next_stride,
+                   const float* prev_xy, float* next_xy, int n,
+                   uint8_t* status, float* err, const dr3o_lk_params* p,
+                   int order, int n_threads);
+
+/* same, but also returns per-point iteration counts per level (iters[n*(L+1)]), may be NULL */
+int  dr3o_lk_track_ex(const uint8_t* prev, const uint8_t* next, int w, int h,
+                      int prev_stride, int next_stride,
+                      const float* prev_xy, float* next_xy, int n,
+                      uint8_t* status, float* err, const dr3o_lk_params* p,
+                      int order, int n_threads, int* iters);
+
+/* src/utils.cpp:382-419 -- 2x2 box half-sampler, dst size (w/2, h/2) (floor). */
+void dr3o_halfsample_u8(const uint8_t* src, int w, int h, int stride,
+                        uint8_t* dst, int dstride, int mode);
+
+/* cv::invert of a 3x3 f64 (closed-form adjugate, DECOMP_LU path for n==3). returns 0 if singular. */
+int  dr3o_invert3x3(const double M[9], double Minv[9]);
+
+/* A-4: cv::warpPerspective(src,dst,M,dsize,INTER_LINEAR,BORDER_CONSTANT,0).  M is the f32 3x3 the
+ * reference passes (forward map unless DR3O_WARP_INVERSE_MAP).  Strides in bytes. */
+int  dr3o_warp_perspective(const void* src, int sw, int sh, int sstride, int type,
+                           void* dst, int dw, int dh, int dstride,
+                           const float M[9], int flags, int n_threads);
+
+/* A-5: cv::remap(src,dst,mapx,mapy,INTER_LINEAR,BORDER_CONSTANT,0) with CV_32FC1 maps. */
+int  dr3o_remap_bilinear(const void* src, int sw, int sh, int sstride, int type,
+                         void* dst, int dw, int dh, int dstride,
+                         const float* mapx, const float* mapy, int map_stride_elems,
+                         int n_threads);
+
+/* src/utils.cpp:282-321 */
+float dr3o_shi_tomasi_score(const uint8_t* img, int w, int h, int stride, int u, int v);
+
+/* src/utils.cpp:125-187 / :203-265 -- spherical / cylindrical map generation (u,v f32 planes w*h) */
+void dr3o_spherical_map(int w, int h, float f, float* u, float* v);
+void dr3o_cylindrical_map(int w, int h, float f, float* u, float* v);
+
+/* src/panorama.cpp:194-212 -- feather multiply + accumulate of one warped 32FC4 image into the
+ * canvas, for columns [min_x,max_x); ramp has (max_x-min_x) entries.  Strides in bytes. */
+void dr3o_feather_accumulate(float* canvas, int cw, int ch, int cstride,
+                             float* warped, int wstride,
+                             int min_x, int max_x, const float* ramp);
+/* src/panorama.cpp:215-229 */
+void dr3o_normalize_canvas(const float* canvas, int cw, int ch, int cstride,
+                           uint8_t* out, int ostride);
+/* include/utils.hpp:37-46 */
+void dr3o_linspace_f32(float a, float b, int n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

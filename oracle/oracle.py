@@ -1,0 +1,249 @@
+"""ctypes front-end of the CPU oracle (oracle/dr3_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED (no reference fixtures exist; OpenCV absent) -- see dr3_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdr3oracle.so")
+
+# pixel types / flags (mirrors dr3_oracle.h)
+T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
+LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
+WARP_INVERSE_MAP = 16
+ORDER_RASTER, ORDER_WAVE64 = 0, 1
+HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
+CRIT_COUNT, CRIT_EPS = 1, 2
+
+
+class LKParams(C.Structure):
+    _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
+                ("crit_type", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
+                ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "dr3_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libdr3oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, ip = C.c_void_p, C.c_int
+        L.dr3o_lk_effective_max_level.argtypes = [ip] * 5
+        L.dr3o_lk_effective_max_level.restype = ip
+        L.dr3o_pyr_down_u8.argtypes = [vp, ip, ip, ip, vp, ip]
+        L.dr3o_pyr_down_u8.restype = None
+        L.dr3o_scharr_s16.argtypes = [vp, ip, ip, ip, vp, ip]
+        L.dr3o_scharr_s16.restype = None
+        L.dr3o_lk_track_ex.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp,
+                                       C.POINTER(LKParams), ip, ip, vp]
+        L.dr3o_lk_track_ex.restype = ip
+        L.dr3o_halfsample_u8.argtypes = [vp, ip, ip, ip, vp, ip, ip]
+        L.dr3o_halfsample_u8.restype = None
+        L.dr3o_invert3x3.argtypes = [vp, vp]
+        L.dr3o_invert3x3.restype = ip
+        L.dr3o_warp_perspective.argtypes = [vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, ip, ip]
+        L.dr3o_warp_perspective.restype = ip
+        L.dr3o_remap_bilinear.argtypes = [vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip]
+        L.dr3o_remap_bilinear.restype = ip
+        L.dr3o_shi_tomasi_score.argtypes = [vp, ip, ip, ip, ip, ip]
+        L.dr3o_shi_tomasi_score.restype = C.c_float
+        L.dr3o_spherical_map.argtypes = [ip, ip, C.c_float, vp, vp]
+        L.dr3o_spherical_map.restype = None
+        L.dr3o_cylindrical_map.argtypes = [ip, ip, C.c_float, vp, vp]
+        L.dr3o_cylindrical_map.restype = None
+        L.dr3o_feather_accumulate.argtypes = [vp, ip, ip, ip, vp, ip, ip, ip, vp]
+        L.dr3o_feather_accumulate.restype = None
+        L.dr3o_normalize_canvas.argtypes = [vp, ip, ip, ip, vp, ip]
+        L.dr3o_normalize_canvas.restype = None
+        L.dr3o_linspace_f32.argtypes = [C.c_float, C.c_float, ip, vp]
+        L.dr3o_linspace_f32.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _gray(img):
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+def lk_effective_max_level(w, h, win_w, win_h, max_level):
+    return lib().dr3o_lk_effective_max_level(w, h, win_w, win_h, max_level)
+
+
+def pyr_down(img):
+    img = _gray(img)
+    h, w = img.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().dr3o_pyr_down_u8(_p(img), w, h, img.strides[0], _p(out), out.strides[0])
+    return out
+
+
+def scharr(img):
+    """returns int16 (h, w, 2): [...,0]=Ix, [...,1]=Iy (x32 scale)"""
+    img = _gray(img)
+    h, w = img.shape
+    out = np.empty((h, w, 2), np.int16)
+    lib().dr3o_scharr_s16(_p(img), w, h, img.strides[0], _p(out), 2 * w)
+    return out
+
+
+def lk_params(win=(21, 21), max_level=3, max_iters=30, eps=0.01, crit_type=CRIT_COUNT | CRIT_EPS,
+              flags=0, min_eig_threshold=1e-4):
+    return LKParams(int(win[0]), int(win[1]), int(max_level), int(crit_type), int(max_iters),
+                    float(eps), int(flags), float(min_eig_threshold))
+
+
+def lk_track(prev, nxt, prev_xy, next_xy0=None, params=None, order=ORDER_RASTER, n_threads=0,
+             want_iters=False):
+    """cv::calcOpticalFlowPyrLK restatement.  Returns (next_xy, status, err, eff_max_level[, iters])."""
+    prev, nxt = _gray(prev), _gray(nxt)
+    assert prev.shape == nxt.shape
+    h, w = prev.shape
+    p = params if params is not None else lk_params()
+    prev_xy = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    n = prev_xy.shape[0]
+    nxt_xy = (prev_xy.copy() if next_xy0 is None
+              else np.ascontiguousarray(next_xy0, np.float32).reshape(-1, 2).copy())
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    eff = lk_effective_max_level(w, h, p.win_w, p.win_h, p.max_level)
+    iters = np.zeros((n, eff + 1), np.int32) if want_iters else None
+    r = lib().dr3o_lk_track_ex(_p(prev), _p(nxt), w, h, prev.strides[0], nxt.strides[0],
+                               _p(prev_xy), _p(nxt_xy), n, _p(status), _p(err), C.byref(p),
+                               order, n_threads, _p(iters) if want_iters else None)
+    if r < 0:
+        raise ValueError("dr3o_lk_track failed: %d" % r)
+    if want_iters:
+        return nxt_xy, status, err, r, iters
+    return nxt_xy, status, err, r
+
+
+def halfsample(img, mode=HALF_TRUNC):
+    img = _gray(img)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), np.uint8)
+    lib().dr3o_halfsample_u8(_p(img), w, h, img.strides[0], _p(out), out.strides[0], mode)
+    return out
+
+
+def halfsample_pyramid(img, n_levels, mode=HALF_TRUNC):
+    """utils::create_img_pyramid (src/utils.cpp:421-430)"""
+    pyr = [_gray(img)]
+    for _ in range(1, n_levels):
+        pyr.append(halfsample(pyr[-1], mode))
+    return pyr
+
+
+def invert3x3(M):
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros(9, np.float64)
+    ok = lib().dr3o_invert3x3(_p(M), _p(out))
+    return out.reshape(3, 3), bool(ok)
+
+
+def _img_type(img):
+    img = np.asarray(img)
+    if img.dtype == np.uint8:
+        if img.ndim == 2:
+            return T_8UC1
+        return {1: T_8UC1, 3: T_8UC3, 4: T_8UC4}[img.shape[2]]
+    if img.dtype == np.float32:
+        if img.ndim == 2:
+            return T_32FC1
+        return {1: T_32FC1, 4: T_32FC4}[img.shape[2]]
+    raise TypeError("unsupported image dtype %s" % img.dtype)
+
+
+def warp_perspective(src, M, dsize, flags=0, n_threads=0):
+    """cv::warpPerspective(src, dst, M, dsize=(W,H)) INTER_LINEAR, BORDER_CONSTANT 0."""
+    src = np.ascontiguousarray(src)
+    t = _img_type(src)
+    sh, sw = src.shape[:2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    dst = np.zeros((dh, dw) + src.shape[2:], src.dtype)
+    M = np.ascontiguousarray(M, np.float32).reshape(9)
+    r = lib().dr3o_warp_perspective(_p(src), sw, sh, src.strides[0], t, _p(dst), dw, dh,
+                                    dst.strides[0], _p(M), flags, n_threads)
+    if r != 0:
+        raise ValueError("dr3o_warp_perspective failed: %d" % r)
+    return dst
+
+
+def remap(src, mapx, mapy, n_threads=0):
+    src = np.ascontiguousarray(src)
+    t = _img_type(src)
+    sh, sw = src.shape[:2]
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    dh, dw = mapx.shape
+    dst = np.zeros((dh, dw) + src.shape[2:], src.dtype)
+    r = lib().dr3o_remap_bilinear(_p(src), sw, sh, src.strides[0], t, _p(dst), dw, dh,
+                                  dst.strides[0], _p(mapx), _p(mapy), dw, n_threads)
+    if r != 0:
+        raise ValueError("dr3o_remap_bilinear failed: %d" % r)
+    return dst
+
+
+def shi_tomasi_score(img, u, v):
+    img = _gray(img)
+    h, w = img.shape
+    return float(lib().dr3o_shi_tomasi_score(_p(img), w, h, img.strides[0], int(u), int(v)))
+
+
+def spherical_map(w, h, f):
+    u = np.empty((h, w), np.float32)
+    v = np.empty((h, w), np.float32)
+    lib().dr3o_spherical_map(w, h, f, _p(u), _p(v))
+    return u, v
+
+
+def cylindrical_map(w, h, f):
+    u = np.empty((h, w), np.float32)
+    v = np.empty((h, w), np.float32)
+    lib().dr3o_cylindrical_map(w, h, f, _p(u), _p(v))
+    return u, v
+
+
+def linspace_f32(a, b, n):
+    out = np.empty(n, np.float32)
+    lib().dr3o_linspace_f32(a, b, n, _p(out))
+    return out
+
+
+def feather_accumulate(canvas, warped, min_x, max_x, ramp):
+    """in-place on canvas and warped (both float32 HxWx4)"""
+    assert canvas.dtype == np.float32 and warped.dtype == np.float32
+    ch, cw = canvas.shape[:2]
+    ramp = np.ascontiguousarray(ramp, np.float32)
+    lib().dr3o_feather_accumulate(_p(canvas), cw, ch, canvas.strides[0], _p(warped),
+                                  warped.strides[0], min_x, max_x, _p(ramp))
+
+
+def normalize_canvas(canvas):
+    ch, cw = canvas.shape[:2]
+    out = np.zeros((ch, cw, 3), np.uint8)
+    lib().dr3o_normalize_canvas(_p(canvas), cw, ch, canvas.strides[0], _p(out), out.strides[0])
+    return out
