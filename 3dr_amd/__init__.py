@@ -1,0 +1,379 @@
+"""3dr_amd -- MI355X (gfx950) implementation of 3DR's dense hot path, behind a C ABI.
+
+The product is ``libdr3hip.so`` (hand-written HIP kernels + the C entry points of
+``include/dr3hip.h``).  This Python package is a thin ctypes mirror of that ABI used by the tests
+and the bench; its function names follow the calls the reference makes
+(``cv::calcOpticalFlowPyrLK`` at src/initialization.cpp:608, ``cv::warpPerspective`` at
+src/stitch.cpp:73-74 / src/panorama.cpp:192, ``cv::remap`` at src/utils.cpp:191,
+``utils::create_img_pyramid`` at src/utils.cpp:421).
+
+There is NO CPU fallback: every compute entry point needs the built library and a HIP device and
+raises ``Dr3HipError`` otherwise.  (The directory name starts with a digit, so import it with
+``importlib.import_module("3dr_amd")``.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdr3hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "dr3hip.h")
+
+# constants of include/dr3hip.h
+T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
+LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
+WARP_INVERSE_MAP = 16
+CRIT_COUNT, CRIT_EPS = 1, 2
+HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
+MAX_LEVELS, MAX_WIN = 8, 32
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF = 0, 1, 2, 3, 4
+
+
+class Dr3HipError(RuntimeError):
+    pass
+
+
+class LKParams(C.Structure):
+    _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
+                ("crit_type", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
+                ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int),
+                ("img_pitch", C.c_int), ("img_slot_step", C.c_size_t), ("img", C.c_void_p),
+                ("der_pitch", C.c_int), ("der_slot_step", C.c_size_t), ("der", C.c_void_p)]
+
+
+class WarpJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("sw", C.c_int), ("sh", C.c_int), ("sstride", C.c_int),
+                ("dst", C.c_void_p), ("dw", C.c_int), ("dh", C.c_int), ("dstride", C.c_int),
+                ("M", C.c_float * 9)]
+
+
+def build(force=False, extra=""):
+    """Compile every HIP source into 3dr_amd/libdr3hip.so (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if extra:
+        cmd.append("EXTRA=" + extra)
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGNATURES = None
+
+
+def _signatures():
+    vp, ip, fp_ = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    P = C.POINTER
+    return {
+        "dr3hip_version": ([], ip),
+        "dr3hip_lk_params_reference": ([P(LKParams)], None),
+        "dr3hip_device_count": ([], ip),
+        "dr3hip_init": ([ip, P(vp)], ip),
+        "dr3hip_destroy": ([vp], None),
+        "dr3hip_last_error": ([vp], C.c_char_p),
+        "dr3hip_sync": ([vp], ip),
+        "dr3hip_stream": ([vp], vp),
+        "dr3hip_malloc": ([vp, C.c_size_t, P(vp)], ip),
+        "dr3hip_free": ([vp, vp], ip),
+        "dr3hip_memcpy_h2d": ([vp, vp, vp, C.c_size_t], ip),
+        "dr3hip_memcpy_d2h": ([vp, vp, vp, C.c_size_t], ip),
+        "dr3hip_memset": ([vp, vp, ip, C.c_size_t], ip),
+        "dr3hip_lk_track": ([vp, vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp, P(LKParams)], ip),
+        "dr3hip_lk_effective_max_level": ([ip] * 5, ip),
+        "dr3hip_halfsample_pyramid": ([vp, vp, ip, ip, ip, ip, ip, P(vp), P(ip)], ip),
+        "dr3hip_warp_perspective": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
+        "dr3hip_remap_bilinear": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
+        "dr3hip_batch_create": ([vp, ip, ip, ip, ip, ip, ip, P(vp)], ip),
+        "dr3hip_batch_destroy": ([vp], None),
+        "dr3hip_batch_levels": ([vp], ip),
+        "dr3hip_batch_bytes": ([vp], C.c_size_t),
+        "dr3hip_batch_level_info": ([vp, ip, P(LevelInfo)], ip),
+        "dr3hip_batch_upload": ([vp, ip, ip, vp, ip, C.c_size_t], ip),
+        "dr3hip_batch_download": ([vp, ip, ip, ip, vp, ip], ip),
+        "dr3hip_batch_build": ([vp, ip, ip, ip], ip),
+        "dr3hip_batch_track": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, P(LKParams)], ip),
+        "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
+        "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
+        "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
+        "dr3hip_timer_start": ([vp], ip),
+        "dr3hip_timer_stop": ([vp, fp_], ip),
+        "dr3hip_profile_enable": ([vp, ip], ip),
+        "dr3hip_profile_read": ([vp, ip, P(C.c_double), P(ip)], ip),
+        "dr3hip_profile_reset": ([vp], ip),
+    }
+
+
+def exported_symbols():
+    """names of every entry point include/dr3hip.h declares (used by the CPU-side ABI test)"""
+    return sorted(_signatures().keys())
+
+
+def lib():
+    """dlopen libdr3hip.so and bind every symbol; loud failure if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Dr3HipError("libdr3hip.so is not built (%s missing): run __graft_entry__.build() "
+                              "or `make -C 3dr_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (argt, rest) in _signatures().items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.argtypes = argt
+            fn.restype = rest
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lk_params(win=(21, 21), max_level=3, max_iters=30, eps=0.01, crit_type=CRIT_COUNT | CRIT_EPS,
+              flags=0, min_eig_threshold=1e-4):
+    return LKParams(int(win[0]), int(win[1]), int(max_level), int(crit_type), int(max_iters),
+                    float(eps), int(flags), float(min_eig_threshold))
+
+
+def lk_params_reference():
+    """the literals of src/initialization.cpp:593-613"""
+    p = LKParams()
+    lib().dr3hip_lk_params_reference(C.byref(p))
+    return p
+
+
+def lk_effective_max_level(w, h, win_w, win_h, max_level):
+    return lib().dr3hip_lk_effective_max_level(w, h, win_w, win_h, max_level)
+
+
+def _img_type(img):
+    if img.dtype == np.uint8:
+        return T_8UC1 if img.ndim == 2 else {1: T_8UC1, 3: T_8UC3, 4: T_8UC4}[img.shape[2]]
+    if img.dtype == np.float32:
+        return T_32FC1 if img.ndim == 2 else {1: T_32FC1, 4: T_32FC4}[img.shape[2]]
+    raise TypeError("unsupported image dtype %s" % img.dtype)
+
+
+class DeviceBuffer:
+    """a device allocation owned by a Context"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._chk(lib().dr3hip_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        self.ctx._chk(lib().dr3hip_memcpy_h2d(self.ctx.h, self.ptr + offset, _p(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype, offset=0):
+        out = np.empty(shape, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        self.ctx._chk(lib().dr3hip_memcpy_d2h(self.ctx.h, _p(out), self.ptr + offset, out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._chk(lib().dr3hip_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib().dr3hip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """one dr3hip_ctx (one GPU, one stream).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.dr3hip_init(int(device), C.byref(h))
+        if rc != 0:
+            raise Dr3HipError("dr3hip_init(%d) failed (%d): %s" % (device, rc, L.dr3hip_last_error(None).decode()))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().dr3hip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise Dr3HipError("dr3hip error %d: %s" % (rc, lib().dr3hip_last_error(self.h).decode()))
+        return rc
+
+    def sync(self):
+        self._chk(lib().dr3hip_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
+
+    # ---- timing --------------------------------------------------------------------------------
+    def timer_start(self):
+        self._chk(lib().dr3hip_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(lib().dr3hip_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._chk(lib().dr3hip_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(lib().dr3hip_profile_reset(self.h))
+
+    def profile_read(self, which):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(lib().dr3hip_profile_read(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- host-buffer drop-in calls -----------------------------------------------------------------
+    def calcOpticalFlowPyrLK(self, prev, nxt, prev_pts, next_pts=None, params=None):
+        """cv::calcOpticalFlowPyrLK (src/initialization.cpp:608-613).
+        Returns (next_pts (n,2) f32, status (n,) u8, err (n,) f32, effective_max_level)."""
+        prev = np.ascontiguousarray(prev); nxt = np.ascontiguousarray(nxt)
+        if prev.dtype != np.uint8 or prev.ndim != 2 or prev.shape != nxt.shape or nxt.dtype != np.uint8:
+            raise ValueError("prev/next must be equal-sized 8-bit gray images")
+        p = params if params is not None else lk_params()
+        prev_pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        n = prev_pts.shape[0]
+        out = (prev_pts.copy() if next_pts is None
+               else np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy())
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        h, w = prev.shape
+        L = self._chk(lib().dr3hip_lk_track(self.h, _p(prev), _p(nxt), w, h, prev.strides[0], nxt.strides[0],
+                                            _p(prev_pts), _p(out), n, _p(status), _p(err), C.byref(p)))
+        return out, status, err, L
+
+    def warpPerspective(self, src, M, dsize, flags=0):
+        """cv::warpPerspective(src, dst, M, dsize=(W,H)) INTER_LINEAR / BORDER_CONSTANT 0
+        (src/stitch.cpp:73-74, src/panorama.cpp:192)."""
+        src = np.ascontiguousarray(src)
+        t = _img_type(src)
+        sh, sw = src.shape[:2]
+        dw, dh = int(dsize[0]), int(dsize[1])
+        dst = np.empty((dh, dw) + src.shape[2:], src.dtype)
+        M = np.ascontiguousarray(M, np.float32).reshape(9)
+        self._chk(lib().dr3hip_warp_perspective(self.h, _p(src), sw, sh, src.strides[0], t, _p(dst), dw, dh,
+                                                dst.strides[0], _p(M), int(flags)))
+        return dst
+
+    def remap(self, src, mapx, mapy):
+        """cv::remap(src, dst, mapx, mapy, INTER_LINEAR) (src/utils.cpp:191)."""
+        src = np.ascontiguousarray(src)
+        t = _img_type(src)
+        sh, sw = src.shape[:2]
+        mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
+        dh, dw = mapx.shape
+        dst = np.empty((dh, dw) + src.shape[2:], src.dtype)
+        self._chk(lib().dr3hip_remap_bilinear(self.h, _p(src), sw, sh, src.strides[0], t, _p(dst), dw, dh,
+                                              dst.strides[0], _p(mapx), _p(mapy), mapx.strides[0]))
+        return dst
+
+    def create_img_pyramid(self, img, n_levels, mode=HALF_REF_X86):
+        """utils::create_img_pyramid (src/utils.cpp:421-430): list of n_levels u8 images."""
+        img = np.ascontiguousarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("8-bit gray image expected")
+        h, w = img.shape
+        pyr = [img]
+        for _ in range(1, n_levels):
+            ph, pw = pyr[-1].shape
+            pyr.append(np.zeros((ph // 2, pw // 2), np.uint8))
+        ptrs = (C.c_void_p * n_levels)(*[a.ctypes.data for a in pyr])
+        strides = (C.c_int * n_levels)(*[a.strides[0] if a.size else 1 for a in pyr])
+        self._chk(lib().dr3hip_halfsample_pyramid(self.h, _p(img), w, h, img.strides[0], n_levels, int(mode),
+                                                  ptrs, strides))
+        return pyr
+
+
+class FrameBatch:
+    """device-resident frame slots with LK pyramids (dr3hip_batch)"""
+
+    def __init__(self, ctx, w, h, win=(21, 21), max_level=3, capacity=2):
+        self.ctx = ctx
+        hb = C.c_void_p()
+        ctx._chk(lib().dr3hip_batch_create(ctx.h, w, h, int(win[0]), int(win[1]), int(max_level), int(capacity),
+                                           C.byref(hb)))
+        self.h = hb
+        self.w, self.h_px, self.capacity = w, h, capacity
+        self.levels = lib().dr3hip_batch_levels(hb)
+        self.nbytes = lib().dr3hip_batch_bytes(hb)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().dr3hip_batch_destroy(self.h)
+            self.h = None
+
+    def level_info(self, level):
+        li = LevelInfo()
+        self.ctx._chk(lib().dr3hip_batch_level_info(self.h, level, C.byref(li)))
+        return li
+
+    def upload(self, first, frames):
+        """frames: (n, h, w) u8 (or a list of (h, w) arrays)"""
+        frames = np.ascontiguousarray(np.asarray(frames, np.uint8))
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, h, w = frames.shape
+        assert (h, w) == (self.h_px, self.w)
+        self.ctx._chk(lib().dr3hip_batch_upload(self.h, first, n, _p(frames), frames.strides[1], frames.strides[0]))
+
+    def build(self, first, count, with_deriv=True):
+        self.ctx._chk(lib().dr3hip_batch_build(self.h, first, count, int(with_deriv)))
+
+    def download_image(self, slot, level):
+        li = self.level_info(level)
+        out = np.empty((li.h, li.w), np.uint8)
+        self.ctx._chk(lib().dr3hip_batch_download(self.h, slot, level, 0, _p(out), out.strides[0]))
+        return out
+
+    def download_deriv(self, slot, level):
+        li = self.level_info(level)
+        out = np.empty((li.h, li.w, 2), np.int16)
+        self.ctx._chk(lib().dr3hip_batch_download(self.h, slot, level, 1, _p(out), out.strides[0]))
+        return out
+
+    def track(self, n_pairs, first_slot, d_prev_xy, d_next_xy, n_pts, d_status, d_err, params,
+              d_prev_slot=None, d_next_slot=None, d_iters=None):
+        """all d_* are DeviceBuffer (or raw device pointers); returns the effective maxLevel"""
+        ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        return self.ctx._chk(lib().dr3hip_batch_track(self.h, n_pairs, first_slot, ptr(d_prev_slot), ptr(d_next_slot),
+                                                      ptr(d_prev_xy), ptr(d_next_xy), n_pts, ptr(d_status),
+                                                      ptr(d_err), ptr(d_iters), C.byref(params)))
+
+
+def warp_batch(ctx, jobs, img_type, flags=0):
+    """jobs: list of dicts(src, sw, sh, sstride, dst, dw, dh, dstride, M) with device pointers"""
+    arr = (WarpJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i].src, arr[i].sw, arr[i].sh, arr[i].sstride = j["src"], j["sw"], j["sh"], j["sstride"]
+        arr[i].dst, arr[i].dw, arr[i].dh, arr[i].dstride = j["dst"], j["dw"], j["dh"], j["dstride"]
+        M = np.asarray(j["M"], np.float32).reshape(9)
+        for k in range(9):
+            arr[i].M[k] = float(M[k])
+    ctx._chk(lib().dr3hip_warp_perspective_batch(ctx.h, arr, len(jobs), int(img_type), int(flags)))

@@ -1,0 +1,680 @@
+// dr3hip_api.cpp -- host side of libdr3hip.so: context, device memory, staging of caller-owned
+// host buffers, and the launch sequences behind each C-ABI entry point of include/dr3hip.h.
+// Compiled by hipcc as host code (-ffp-contract=off: the homography inversion below must round
+// like cv::invert does on the reference's x86-64 build).
+#include "dr3hip_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace dr3;
+
+// -------------------------------------------------------------------------------------------------
+struct ProfEvent { int which; hipEvent_t e0, e1; };
+
+struct dr3hip_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // grow-only staging buffers for the host-buffer calls
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf stage[6];
+    dr3hip_batch* lk_batch = nullptr;     // cached 2-slot batch behind dr3hip_lk_track
+    bool prof = false;
+    double prof_ms[5] = {0, 0, 0, 0, 0};
+    int prof_n[5] = {0, 0, 0, 0, 0};
+    std::vector<ProfEvent> pending;
+};
+
+struct dr3hip_batch {
+    dr3hip_ctx* ctx = nullptr;
+    int w = 0, h = 0, win_w = 0, win_h = 0, levels = 0, capacity = 0;
+    LevelDev lv[DR3HIP_MAX_LEVELS];
+    size_t bytes = 0;
+};
+
+static std::string g_init_err;
+
+static int fail(dr3hip_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_init_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+    do { hipError_t e_ = (call);                                                                   \
+         if (e_ != hipSuccess) return fail((ctx), DR3HIP_EHIP, "%s: %s (%s:%d)", #call,          \
+                                           hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct DeviceGuard {          // every entry point runs with the ctx's device current
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int stage_reserve(dr3hip_ctx* ctx, int idx, size_t bytes)
+{
+    dr3hip_ctx::Buf& b = ctx->stage[idx];
+    if (b.cap >= bytes) return DR3HIP_OK;
+    if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&b.p, cap) != hipSuccess) { b.p = nullptr; return fail(ctx, DR3HIP_ENOMEM, "hipMalloc(%zu) failed", cap); }
+    b.cap = cap;
+    return DR3HIP_OK;
+}
+
+// ---- profiling brackets ----------------------------------------------------------------------------
+static void prof_begin(dr3hip_ctx* ctx, int which, ProfEvent& pe)
+{
+    pe.which = -1;
+    if (!ctx->prof) return;
+    if (hipEventCreate(&pe.e0) != hipSuccess) return;
+    if (hipEventCreate(&pe.e1) != hipSuccess) { (void)hipEventDestroy(pe.e0); return; }
+    pe.which = which;
+    (void)hipEventRecord(pe.e0, ctx->stream);
+}
+static void prof_end(dr3hip_ctx* ctx, ProfEvent& pe)
+{
+    if (pe.which < 0) return;
+    (void)hipEventRecord(pe.e1, ctx->stream);
+    ctx->pending.push_back(pe);
+}
+static void prof_drain(dr3hip_ctx* ctx)
+{
+    for (ProfEvent& pe : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+            ctx->prof_ms[pe.which] += ms; ctx->prof_n[pe.which] += 1;
+        }
+        (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1);
+    }
+    ctx->pending.clear();
+}
+
+// =================================================================================================
+extern "C" {
+
+int dr3hip_version(void) { return DR3HIP_VERSION; }
+
+void dr3hip_lk_params_reference(dr3hip_lk_params* p)
+{
+    if (!p) return;
+    p->win_w = 30; p->win_h = 30;          // klt_win_size, src/initialization.cpp:593
+    p->max_level = 4;                       // :613
+    p->crit_type = DR3HIP_CRIT_COUNT | DR3HIP_CRIT_EPS;   // :598
+    p->max_iters = 1000;                    // klt_max_iter :594
+    p->eps = 1e-3;                          // klt_eps :595
+    p->flags = DR3HIP_LK_USE_INITIAL_FLOW;  // :613
+    p->min_eig_threshold = 1e-4;            // OpenCV default argument
+}
+
+int dr3hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dr3hip_init(int device, dr3hip_ctx** out)
+{
+    if (!out) return fail(nullptr, DR3HIP_EINVAL, "dr3hip_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, DR3HIP_ENODEV, "dr3hip_init: no HIP device (%s); libdr3hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(nullptr, DR3HIP_EINVAL, "dr3hip_init: device %d out of range [0,%d)", device, n);
+    dr3hip_ctx* ctx = new (std::nothrow) dr3hip_ctx();
+    if (!ctx) return fail(nullptr, DR3HIP_ENOMEM, "dr3hip_init: out of host memory");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->t0)) != hipSuccess || (e = hipEventCreate(&ctx->t1)) != hipSuccess) {
+        fail(nullptr, DR3HIP_EHIP, "dr3hip_init: %s", hipGetErrorString(e));
+        delete ctx;
+        return DR3HIP_EHIP;
+    }
+    *out = ctx;
+    return DR3HIP_OK;
+}
+
+void dr3hip_destroy(dr3hip_ctx* ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
+    for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* dr3hip_last_error(const dr3hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+int dr3hip_sync(dr3hip_ctx* ctx)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+void* dr3hip_stream(dr3hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int dr3hip_malloc(dr3hip_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    *dptr = nullptr;
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) { *dptr = nullptr; return fail(ctx, DR3HIP_ENOMEM, "hipMalloc(%zu) failed", bytes); }
+    return DR3HIP_OK;
+}
+int dr3hip_free(dr3hip_ctx* ctx, void* dptr)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!dptr) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(dptr));
+    return DR3HIP_OK;
+}
+int dr3hip_memcpy_h2d(dr3hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+int dr3hip_memcpy_d2h(dr3hip_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+int dr3hip_memset(dr3hip_ctx* ctx, void* dst, int value, size_t bytes)
+{
+    if (!ctx || (bytes && !dst)) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return DR3HIP_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------------------
+int dr3hip_timer_start(dr3hip_ctx* ctx)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return DR3HIP_OK;
+}
+int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return DR3HIP_OK;
+}
+int dr3hip_profile_enable(dr3hip_ctx* ctx, int on)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    ctx->prof = on != 0;
+    return DR3HIP_OK;
+}
+int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n)
+{
+    if (!ctx || which < 0 || which >= 5) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    prof_drain(ctx);
+    if (total_ms) *total_ms = ctx->prof_ms[which];
+    if (n) *n = ctx->prof_n[which];
+    return DR3HIP_OK;
+}
+int dr3hip_profile_reset(dr3hip_ctx* ctx)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    prof_drain(ctx);
+    for (int i = 0; i < 5; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    return DR3HIP_OK;
+}
+
+// ---- LK geometry ----------------------------------------------------------------------------------
+int dr3hip_lk_effective_max_level(int w, int h, int win_w, int win_h, int max_level)
+{
+    // cv::buildOpticalFlowPyramid's early stop
+    for (int level = 0; level <= max_level; ++level) {
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win_w || h <= win_h) return level;
+    }
+    return max_level;
+}
+
+// ---- batch ---------------------------------------------------------------------------------------
+int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int max_level,
+                        int capacity, dr3hip_batch** out)
+{
+    if (!ctx || !out) return DR3HIP_EINVAL;
+    *out = nullptr;
+    if (w < 4 || h < 4 || capacity < 1 || max_level < 0 || win_w <= 2 || win_h <= 2)
+        return fail(ctx, DR3HIP_EINVAL, "batch_create: bad geometry w=%d h=%d win=%dx%d maxLevel=%d capacity=%d", w, h, win_w, win_h, max_level, capacity);
+    if (max_level >= DR3HIP_MAX_LEVELS) return fail(ctx, DR3HIP_ERANGE, "batch_create: maxLevel %d >= %d", max_level, DR3HIP_MAX_LEVELS);
+    if (win_w > DR3HIP_MAX_WIN || win_h > DR3HIP_MAX_WIN || ((win_w + 3) / 4) * win_h > 256)
+        return fail(ctx, DR3HIP_ERANGE, "batch_create: window %dx%d exceeds this build's limit (%d)", win_w, win_h, DR3HIP_MAX_WIN);
+    DeviceGuard g(ctx->device);
+    dr3hip_batch* b = new (std::nothrow) dr3hip_batch();
+    if (!b) return fail(ctx, DR3HIP_ENOMEM, "batch_create: out of host memory");
+    b->ctx = ctx; b->w = w; b->h = h; b->win_w = win_w; b->win_h = win_h; b->capacity = capacity;
+    const int L = dr3hip_lk_effective_max_level(w, h, win_w, win_h, max_level);
+    b->levels = L + 1;
+    memset(b->lv, 0, sizeof(b->lv));
+    int lw = w, lh = h;
+    for (int l = 0; l <= L; ++l) {
+        LevelDev& v = b->lv[l];
+        v.w = lw; v.h = lh;
+        v.pitch = align_up(lw + 8, 64);
+        v.dpitch = align_up(4 * lw + 16, 128);
+        v.step = (long long)align_up(v.pitch * lh, 256);
+        v.dstep = (long long)align_up(v.dpitch * lh, 256);
+        const size_t ib = (size_t)v.step * capacity + 256, db = (size_t)v.dstep * capacity + 256;
+        void *pi = nullptr, *pd = nullptr;
+        if (hipMalloc(&pi, ib) != hipSuccess || hipMalloc(&pd, db) != hipSuccess) {
+            if (pi) (void)hipFree(pi);
+            v.img = nullptr; v.der = nullptr;
+            dr3hip_batch_destroy(b);
+            return fail(ctx, DR3HIP_ENOMEM, "batch_create: hipMalloc failed at level %d (%zu + %zu bytes)", l, ib, db);
+        }
+        v.img = (uint8_t*)pi; v.der = (int16_t*)pd;
+        // pitch slack is read (never used) by aligned over-reads: keep it defined
+        (void)hipMemsetAsync(pi, 0, ib, ctx->stream);
+        (void)hipMemsetAsync(pd, 0, db, ctx->stream);
+        b->bytes += ib + db;
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = b;
+    return DR3HIP_OK;
+}
+
+void dr3hip_batch_destroy(dr3hip_batch* b)
+{
+    if (!b) return;
+    DeviceGuard g(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    for (int l = 0; l < DR3HIP_MAX_LEVELS; ++l) {
+        if (b->lv[l].img) (void)hipFree(b->lv[l].img);
+        if (b->lv[l].der) (void)hipFree(b->lv[l].der);
+    }
+    if (b->ctx->lk_batch == b) b->ctx->lk_batch = nullptr;
+    delete b;
+}
+
+int dr3hip_batch_levels(const dr3hip_batch* b) { return b ? b->levels : DR3HIP_EINVAL; }
+size_t dr3hip_batch_bytes(const dr3hip_batch* b) { return b ? b->bytes : 0; }
+
+int dr3hip_batch_level_info(const dr3hip_batch* b, int level, dr3hip_level_info* out)
+{
+    if (!b || !out || level < 0 || level >= b->levels) return DR3HIP_EINVAL;
+    const LevelDev& v = b->lv[level];
+    out->w = v.w; out->h = v.h;
+    out->img_pitch = v.pitch; out->img_slot_step = (size_t)v.step; out->img = v.img;
+    out->der_pitch = v.dpitch; out->der_slot_step = (size_t)v.dstep; out->der = v.der;
+    return DR3HIP_OK;
+}
+
+int dr3hip_batch_upload(dr3hip_batch* b, int first, int count, const uint8_t* frames, int stride, size_t frame_step)
+{
+    if (!b || !frames || first < 0 || count < 0 || first + count > b->capacity || stride < b->w)
+        return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_upload: bad arguments") : DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    DeviceGuard g(ctx->device);
+    const LevelDev& v = b->lv[0];
+    for (int i = 0; i < count; ++i)
+        HIPCHK(ctx, hipMemcpy2DAsync(v.img + (size_t)(first + i) * v.step, v.pitch, frames + (size_t)i * frame_step, stride,
+                                     b->w, b->h, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void* host, int host_stride)
+{
+    if (!b || !host || slot < 0 || slot >= b->capacity || level < 0 || level >= b->levels || (what != 0 && what != 1))
+        return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_download: bad arguments") : DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    DeviceGuard g(ctx->device);
+    const LevelDev& v = b->lv[level];
+    if (what == 0)
+        HIPCHK(ctx, hipMemcpy2DAsync(host, host_stride, v.img + (size_t)slot * v.step, v.pitch, v.w, v.h, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        HIPCHK(ctx, hipMemcpy2DAsync(host, host_stride, (uint8_t*)v.der + (size_t)slot * v.dstep, v.dpitch, (size_t)4 * v.w, v.h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
+{
+    if (!b || first < 0 || count < 0 || first + count > b->capacity)
+        return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_build: slots [%d,%d) outside capacity %d", first, first + count, b->capacity) : DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    if (count == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    ProfEvent pe; prof_begin(ctx, 0, pe);
+    const int L = b->levels - 1;
+    for (int l = 0; l <= L; ++l) {
+        const bool down = l < L, deriv = with_deriv != 0;
+        if (!down && !deriv) continue;
+        for (int s0 = 0; s0 < count; s0 += 32768) {            // grid.z limit
+            PyrArgs a;
+            a.src = b->lv[l];
+            a.dst = down ? b->lv[l + 1] : b->lv[l];
+            a.first = first + s0;
+            const int n = count - s0 < 32768 ? count - s0 : 32768;
+            HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, ctx->stream));
+        }
+    }
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+static int fill_lk_args(dr3hip_batch* b, const dr3hip_lk_params* p, LKArgs& a)
+{
+    dr3hip_ctx* ctx = b->ctx;
+    if (p->win_w != b->win_w || p->win_h != b->win_h)
+        return fail(ctx, DR3HIP_EINVAL, "track: window %dx%d differs from the batch's %dx%d", p->win_w, p->win_h, b->win_w, b->win_h);
+    const int L = dr3hip_lk_effective_max_level(b->w, b->h, p->win_w, p->win_h, p->max_level);
+    if (L + 1 > b->levels)
+        return fail(ctx, DR3HIP_EINVAL, "track: needs %d levels, batch holds %d", L + 1, b->levels);
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l <= L; ++l) a.lv[l] = b->lv[l];
+    a.max_level = L;
+    a.win_w = p->win_w; a.win_h = p->win_h;
+    a.rpr = (p->win_w + 3) / 4;
+    a.n_items = a.rpr * p->win_h;
+    // TermCriteria clamping of SparsePyrLKOpticalFlowImpl::calc
+    a.max_count = (p->crit_type & DR3HIP_CRIT_COUNT) ? (p->max_iters < 0 ? 0 : p->max_iters > 100 ? 100 : p->max_iters) : 30;
+    double eps = (p->crit_type & DR3HIP_CRIT_EPS) ? (p->eps < 0. ? 0. : p->eps > 10. ? 10. : p->eps) : 0.01;
+    a.epsilon = eps * eps;
+    a.flags = p->flags;
+    a.min_eig = p->min_eig_threshold;
+    return L;
+}
+
+int dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
+                       const int* d_prev_slot, const int* d_next_slot,
+                       const float* d_prev_xy, float* d_next_xy, int n_pts,
+                       uint8_t* d_status, float* d_err, int* d_iters, const dr3hip_lk_params* p)
+{
+    if (!b) return DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    if (!p || n_pairs < 0 || n_pts < 0 || !d_prev_xy || !d_next_xy || !d_status || !d_err)
+        return fail(ctx, DR3HIP_EINVAL, "batch_track: bad arguments");
+    if (!d_prev_slot != !d_next_slot) return fail(ctx, DR3HIP_EINVAL, "batch_track: give both slot arrays or neither");
+    if (!d_prev_slot && (first_slot < 0 || first_slot + n_pairs + 1 > b->capacity))
+        return fail(ctx, DR3HIP_EINVAL, "batch_track: pairs [%d,%d] outside capacity %d", first_slot, first_slot + n_pairs, b->capacity);
+    LKArgs a;
+    const int L = fill_lk_args(b, p, a);
+    if (L < 0) return L;
+    if (n_pairs == 0 || n_pts == 0) return L;
+    DeviceGuard g(ctx->device);
+    ProfEvent pe; prof_begin(ctx, 1, pe);
+    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {              // grid.y limit
+        const int n = n_pairs - p0 < 32768 ? n_pairs - p0 : 32768;
+        const size_t off = (size_t)p0 * n_pts;
+        a.n_pts = n_pts;
+        a.first_slot = first_slot + p0;
+        a.prev_slot = d_prev_slot ? d_prev_slot + p0 : nullptr;
+        a.next_slot = d_next_slot ? d_next_slot + p0 : nullptr;
+        a.prev_xy = d_prev_xy + 2 * off; a.next_xy = d_next_xy + 2 * off;
+        a.status = d_status + off; a.err = d_err + off;
+        a.iters = d_iters ? d_iters + off * (L + 1) : nullptr;
+        HIPCHK(ctx, launch_lk_track(a, n, ctx->stream));
+    }
+    prof_end(ctx, pe);
+    return L;
+}
+
+// ---- host-buffer LK -------------------------------------------------------------------------------
+int dr3hip_lk_track(dr3hip_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h,
+                    int prev_stride, int next_stride, const float* prev_xy, float* next_xy, int n,
+                    uint8_t* status, float* err, const dr3hip_lk_params* p)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!prev || !next || !p || n < 0 || (n && (!prev_xy || !next_xy || !status || !err)) || prev_stride < w || next_stride < w)
+        return fail(ctx, DR3HIP_EINVAL, "lk_track: bad arguments");
+    DeviceGuard g(ctx->device);
+    dr3hip_batch* b = ctx->lk_batch;
+    const int L = dr3hip_lk_effective_max_level(w, h, p->win_w, p->win_h, p->max_level);
+    if (!b || b->w != w || b->h != h || b->win_w != p->win_w || b->win_h != p->win_h || b->levels != L + 1) {
+        if (b) dr3hip_batch_destroy(b);
+        ctx->lk_batch = nullptr;
+        const int rc = dr3hip_batch_create(ctx, w, h, p->win_w, p->win_h, p->max_level, 2, &b);
+        if (rc != DR3HIP_OK) return rc;
+        ctx->lk_batch = b;
+    }
+    int rc;
+    if ((rc = dr3hip_batch_upload(b, 0, 1, prev, prev_stride, 0)) != DR3HIP_OK) return rc;
+    if ((rc = dr3hip_batch_upload(b, 1, 1, next, next_stride, 0)) != DR3HIP_OK) return rc;
+    if ((rc = dr3hip_batch_build(b, 0, 1, 1)) != DR3HIP_OK) return rc;
+    if ((rc = dr3hip_batch_build(b, 1, 1, 0)) != DR3HIP_OK) return rc;
+    if (n == 0) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return L; }
+
+    const size_t xyb = (size_t)n * 2 * sizeof(float);
+    if ((rc = stage_reserve(ctx, 0, xyb)) || (rc = stage_reserve(ctx, 1, xyb)) ||
+        (rc = stage_reserve(ctx, 2, (size_t)n)) || (rc = stage_reserve(ctx, 3, (size_t)n * sizeof(float)))) return rc;
+    float* d_prev = (float*)ctx->stage[0].p; float* d_next = (float*)ctx->stage[1].p;
+    uint8_t* d_status = (uint8_t*)ctx->stage[2].p; float* d_err = (float*)ctx->stage[3].p;
+    HIPCHK(ctx, hipMemcpyAsync(d_prev, prev_xy, xyb, hipMemcpyHostToDevice, ctx->stream));
+    // without USE_INITIAL_FLOW OpenCV never reads nextPts; seed with prevPts so the upload is defined
+    HIPCHK(ctx, hipMemcpyAsync(d_next, (p->flags & DR3HIP_LK_USE_INITIAL_FLOW) ? next_xy : prev_xy, xyb, hipMemcpyHostToDevice, ctx->stream));
+    rc = dr3hip_batch_track(b, 1, 0, nullptr, nullptr, d_prev, d_next, n, d_status, d_err, nullptr, p);
+    if (rc < 0) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(next_xy, d_next, xyb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(status, d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(err, d_err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+// ---- half-sample pyramid ------------------------------------------------------------------------------
+static int resolve_half_mode(int mode, int w)
+{
+    if (mode == DR3HIP_HALF_REF_X86) return (w % 16 == 0) ? DR3HIP_HALF_SSE2 : DR3HIP_HALF_REF_SCALAR;
+    return mode;
+}
+
+int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
+                          uint8_t* d_dst, int dstride, int mode)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_src || !d_dst || w < 2 || h < 2 || sstride < w || dstride < w / 2 || mode < 0 || mode > 3)
+        return fail(ctx, DR3HIP_EINVAL, "halfsample: bad arguments");
+    DeviceGuard g(ctx->device);
+    HalfArgs a;
+    a.src = d_src; a.w = w; a.h = h; a.sstride = sstride;
+    a.dst = d_dst; a.ow = w / 2; a.oh = h / 2; a.dstride = dstride;
+    a.mode = resolve_half_mode(mode, w);
+    ProfEvent pe; prof_begin(ctx, 4, pe);
+    HIPCHK(ctx, launch_halfsample(a, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_halfsample_pyramid(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                              int n_levels, int mode, uint8_t* const* out_levels, const int* out_strides)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!img || w < 1 || h < 1 || stride < w || n_levels < 1 || n_levels > 16 || (n_levels > 1 && (!out_levels || !out_strides)))
+        return fail(ctx, DR3HIP_EINVAL, "halfsample_pyramid: bad arguments");
+    if (n_levels == 1) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    // device layout: level l tightly pitched at align(w_l, 64); REF_SCALAR needs stride == the
+    // caller's stride semantics, so level 0 keeps the caller's stride when it is the walk's input
+    int rc;
+    std::vector<int> lw(n_levels), lh(n_levels), lp(n_levels);
+    std::vector<size_t> off(n_levels);
+    size_t total = 0;
+    lw[0] = w; lh[0] = h;
+    for (int l = 0; l < n_levels; ++l) {
+        if (l) { lw[l] = lw[l - 1] / 2; lh[l] = lh[l - 1] / 2; }
+        // the reference's scalar walk depends on the source stride: cv::Mat levels are continuous
+        // (stride == cols) and level 0 has the caller's stride; mirror both.
+        lp[l] = (l == 0) ? stride : lw[l];
+        off[l] = total;
+        total += (size_t)align_up(lp[l] * (lh[l] > 0 ? lh[l] : 1) + 64, 256);
+    }
+    if ((rc = stage_reserve(ctx, 4, total))) return rc;
+    uint8_t* base = (uint8_t*)ctx->stage[4].p;
+    HIPCHK(ctx, hipMemcpyAsync(base + off[0], img, (size_t)stride * (h - 1) + w, hipMemcpyHostToDevice, ctx->stream));
+    for (int l = 1; l < n_levels; ++l) {
+        if (lw[l] < 1 || lh[l] < 1) break;
+        if ((rc = dr3hip_halfsample_dev(ctx, base + off[l - 1], lw[l - 1], lh[l - 1], lp[l - 1], base + off[l], lp[l], mode))) return rc;
+        if (!out_levels[l] || out_strides[l] < lw[l]) return fail(ctx, DR3HIP_EINVAL, "halfsample_pyramid: out level %d missing or stride too small", l);
+        HIPCHK(ctx, hipMemcpy2DAsync(out_levels[l], out_strides[l], base + off[l], lp[l], lw[l], lh[l], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+// ---- warp -----------------------------------------------------------------------------------------
+// cv::invert for a 3x3 CV_64F matrix (closed-form adjugate); returns false when singular
+static bool invert3x3(const double S[9], double T[9])
+{
+    const double d0 = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d0 == 0.) { for (int i = 0; i < 9; ++i) T[i] = 0.; return false; }
+    const double d = 1. / d0;
+    double t[9];
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d; t[1] = (S[2] * S[7] - S[1] * S[8]) * d; t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d; t[4] = (S[0] * S[8] - S[2] * S[6]) * d; t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d; t[7] = (S[1] * S[6] - S[0] * S[7]) * d; t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    for (int i = 0; i < 9; ++i) T[i] = t[i];
+    return true;
+}
+
+static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
+                     const float M[9], int flags)
+{
+    j.src = (const uint8_t*)src; j.sw = sw; j.sh = sh; j.sstride = sstride;
+    j.dst = (uint8_t*)dst; j.dw = dw; j.dh = dh; j.dstride = dstride;
+    double Md[9];
+    for (int i = 0; i < 9; ++i) Md[i] = (double)M[i];                     // M0.convertTo(matM, CV_64F)
+    if (!(flags & DR3HIP_WARP_INVERSE_MAP)) invert3x3(Md, Md);            // invert(matM, matM)
+    for (int i = 0; i < 9; ++i) j.M[i] = Md[i];
+    // WarpPerspectiveInvoker block geometry (only the x0 + x1 split is observable)
+    const int bh0 = dh < 16 ? dh : 16;
+    j.bw0 = (1024 / bh0) < dw ? (1024 / bh0) : dw;
+}
+
+int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs, int type, int flags)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!jobs || n_jobs < 0 || type_channels(type) == 0) return fail(ctx, DR3HIP_EINVAL, "warp_batch: bad arguments");
+    if (n_jobs == 0) return DR3HIP_OK;
+    if (n_jobs > 65535) return fail(ctx, DR3HIP_ERANGE, "warp_batch: more than 65535 jobs in one call");
+    DeviceGuard g(ctx->device);
+    const int esz = type_elem_bytes(type);
+    std::vector<WarpJobDev> hj(n_jobs);
+    int max_dw = 0, max_dh = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const dr3hip_warp_job& q = jobs[i];
+        if (!q.src || !q.dst || q.sw < 1 || q.sh < 1 || q.dw < 1 || q.dh < 1 || q.sstride < q.sw * esz || q.dstride < q.dw * esz)
+            return fail(ctx, DR3HIP_EINVAL, "warp_batch: job %d has bad geometry", i);
+        if (esz >= 4 && (((uintptr_t)q.src | (uintptr_t)q.dst | (uintptr_t)q.sstride | (uintptr_t)q.dstride) & (uintptr_t)(esz - 1)))
+            return fail(ctx, DR3HIP_EINVAL, "warp_batch: job %d pointers/strides must be %d-byte aligned", i, esz);
+        make_job(hj[i], q.src, q.sw, q.sh, q.sstride, q.dst, q.dw, q.dh, q.dstride, q.M, flags);
+        if (q.dw > max_dw) max_dw = q.dw;
+        if (q.dh > max_dh) max_dh = q.dh;
+    }
+    int rc;
+    if ((rc = stage_reserve(ctx, 5, sizeof(WarpJobDev) * (size_t)n_jobs))) return rc;
+    // pageable source is copied out at enqueue time by hipMemcpyAsync, so hj may die at return
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[5].p, hj.data(), sizeof(WarpJobDev) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ProfEvent pe; prof_begin(ctx, 2, pe);
+    HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p, n_jobs, max_dw, max_dh, type, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_warp_perspective(dr3hip_ctx* ctx, const void* src, int sw, int sh, int sstride, int type,
+                            void* dst, int dw, int dh, int dstride, const float M[9], int flags)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    const int esz = type_elem_bytes(type);
+    if (!src || !dst || !M || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw * esz || dstride < dw * esz)
+        return fail(ctx, DR3HIP_EINVAL, "warp_perspective: bad arguments");
+    DeviceGuard g(ctx->device);
+    const int sp = align_up(sw * esz, 64), dp = align_up(dw * esz, 64);
+    int rc;
+    if ((rc = stage_reserve(ctx, 0, (size_t)sp * sh + 64)) || (rc = stage_reserve(ctx, 1, (size_t)dp * dh + 64))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0].p, sp, src, sstride, (size_t)sw * esz, sh, hipMemcpyHostToDevice, ctx->stream));
+    dr3hip_warp_job j;
+    j.src = ctx->stage[0].p; j.sw = sw; j.sh = sh; j.sstride = sp;
+    j.dst = ctx->stage[1].p; j.dw = dw; j.dh = dh; j.dstride = dp;
+    memcpy(j.M, M, sizeof(j.M));
+    if ((rc = dr3hip_warp_perspective_batch(ctx, &j, 1, type, flags))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(dst, dstride, ctx->stage[1].p, dp, (size_t)dw * esz, dh, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx, const void* d_src, int sw, int sh, int sstride, int type,
+                              void* d_dst, int dw, int dh, int dstride,
+                              const float* d_mapx, const float* d_mapy, int map_stride)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    const int esz = type_elem_bytes(type);
+    if (!d_src || !d_dst || !d_mapx || !d_mapy || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 ||
+        sstride < sw * esz || dstride < dw * esz || map_stride < dw * 4 || (map_stride & 3))
+        return fail(ctx, DR3HIP_EINVAL, "remap: bad arguments");
+    if (esz >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst | (uintptr_t)sstride | (uintptr_t)dstride) & (uintptr_t)(esz - 1)))
+        return fail(ctx, DR3HIP_EINVAL, "remap: pointers/strides must be %d-byte aligned", esz);
+    DeviceGuard g(ctx->device);
+    RemapArgs a;
+    a.src = (const uint8_t*)d_src; a.sw = sw; a.sh = sh; a.sstride = sstride;
+    a.dst = (uint8_t*)d_dst; a.dw = dw; a.dh = dh; a.dstride = dstride;
+    a.mapx = d_mapx; a.mapy = d_mapy; a.map_stride = map_stride;
+    ProfEvent pe; prof_begin(ctx, 3, pe);
+    HIPCHK(ctx, launch_remap(a, type, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_remap_bilinear(dr3hip_ctx* ctx, const void* src, int sw, int sh, int sstride, int type,
+                          void* dst, int dw, int dh, int dstride,
+                          const float* mapx, const float* mapy, int map_stride)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    const int esz = type_elem_bytes(type);
+    if (!src || !dst || !mapx || !mapy || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 ||
+        sstride < sw * esz || dstride < dw * esz || map_stride < dw * 4)
+        return fail(ctx, DR3HIP_EINVAL, "remap: bad arguments");
+    DeviceGuard g(ctx->device);
+    const int sp = align_up(sw * esz, 64), dp = align_up(dw * esz, 64), mp = align_up(dw * 4, 64);
+    int rc;
+    if ((rc = stage_reserve(ctx, 0, (size_t)sp * sh + 64)) || (rc = stage_reserve(ctx, 1, (size_t)dp * dh + 64)) ||
+        (rc = stage_reserve(ctx, 2, (size_t)mp * dh)) || (rc = stage_reserve(ctx, 3, (size_t)mp * dh))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0].p, sp, src, sstride, (size_t)sw * esz, sh, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[2].p, mp, mapx, map_stride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[3].p, mp, mapy, map_stride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = dr3hip_remap_bilinear_dev(ctx, ctx->stage[0].p, sw, sh, sp, type, ctx->stage[1].p, dw, dh, dp,
+                                        (const float*)ctx->stage[2].p, (const float*)ctx->stage[3].p, mp))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(dst, dstride, ctx->stage[1].p, dp, (size_t)dw * esz, dh, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+}  // extern "C"

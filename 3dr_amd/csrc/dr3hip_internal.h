@@ -1,0 +1,88 @@
+// dr3hip_internal.h -- shared between the host API (dr3hip_api.cpp) and the kernel launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/dr3hip.h"
+
+namespace dr3 {
+
+// ---- device-side argument blocks (passed by value as kernel arguments) -----------------------
+
+// one pyramid level of a frame batch
+struct LevelDev {
+    uint8_t* img;          // u8 plane of slot 0
+    int16_t* der;          // interleaved (Ix,Iy) plane of slot 0
+    int w, h;
+    int pitch;             // bytes per image row   (>= w + 4, multiple of 64)
+    int dpitch;            // bytes per derivative row (>= 4*w, multiple of 128)
+    long long step;        // bytes between slots (image)
+    long long dstep;       // bytes between slots (derivative)
+};
+
+struct PyrArgs {
+    LevelDev src;          // level l
+    LevelDev dst;          // level l + 1 (unused when !DOWN)
+    int first;             // first slot; blockIdx.z is added
+};
+
+struct LKArgs {
+    LevelDev lv[DR3HIP_MAX_LEVELS];
+    int max_level;
+    int win_w, win_h;
+    int rpr;               // runs (of 4 taps) per window row = ceil(win_w / 4)
+    int n_items;           // rpr * win_h lane-items per window
+    int max_count;         // clamped iteration limit
+    int flags;
+    int n_pts;
+    int first_slot;
+    double epsilon;        // clamped and squared
+    double min_eig;
+    const int* prev_slot;
+    const int* next_slot;
+    const float* prev_xy;
+    float* next_xy;
+    uint8_t* status;
+    float* err;
+    int* iters;
+};
+
+struct WarpJobDev {
+    const uint8_t* src; int sw, sh, sstride;
+    uint8_t* dst;       int dw, dh, dstride;
+    double M[9];        // inverse map (dst -> src), already inverted on the host
+    int bw0;            // WarpPerspectiveInvoker block width (x0/x1 split)
+};
+
+struct RemapArgs {
+    const uint8_t* src; int sw, sh, sstride;
+    uint8_t* dst;       int dw, dh, dstride;
+    const float* mapx; const float* mapy; int map_stride;   // bytes
+};
+
+struct HalfArgs {
+    const uint8_t* src; int w, h, sstride;
+    uint8_t* dst;       int ow, oh, dstride;
+    int mode;           // DR3HIP_HALF_TRUNC / _SSE2 / _REF_SCALAR (REF_X86 resolved on the host)
+};
+
+// ---- kernel launchers (defined in the .hip files) ----------------------------------------------
+hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, hipStream_t s);
+hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
+hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, hipStream_t s);
+hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
+hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
+
+// geometry helpers shared by host and launchers
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline int type_channels(int type) {
+    switch (type) { case DR3HIP_8UC1: return 1; case DR3HIP_8UC3: return 3; case DR3HIP_8UC4: return 4;
+                    case DR3HIP_32FC4: return 4; case DR3HIP_32FC1: return 1; default: return 0; }
+}
+static inline int type_elem_bytes(int type) {
+    return type_channels(type) * ((type == DR3HIP_32FC4 || type == DR3HIP_32FC1) ? 4 : 1);
+}
+
+}  // namespace dr3

@@ -1,0 +1,162 @@
+// pyr_kernels.hip -- fused Gaussian pyrDown + Scharr derivative pass for one pyramid level of a
+// frame batch (gfx950).  Replaces what cv::calcOpticalFlowPyrLK builds internally from the two
+// images the reference passes at src/initialization.cpp:608-609: buildOpticalFlowPyramid/pyrDown
+//  and calcSharrDeriv (A-2).  Integer-exact.
+//
+// One 256-thread workgroup owns a TW x TH tile of level l of one frame.  The tile plus its halo
+// (2 rows above/below, 4 aligned bytes left/right) is loaded ONCE from HBM with coalesced dword row
+// loads into LDS; REFLECT_101 is applied as a row-index reflection at load time and as a column
+// patch in LDS.  From that tile the workgroup emits
+//   - the level-l derivative tile: interleaved (Ix,Iy) int16, one 16-byte store per lane
+//     (4 pixels), i.e. 1 KiB contiguous per wave-instruction;
+//   - the level-(l+1) image tile (TW/2 x TH/2), one dword store per lane.
+// HBM traffic per level-l pixel: 1 B read (+ halo re-reads served by L2), 4 B + 0.25 B written.
+#include "dr3hip_internal.h"
+
+namespace dr3 {
+namespace {
+
+constexpr int TW = 128;            // tile width  (level-l pixels), multiple of 8
+constexpr int TH = 32;             // tile height, even
+constexpr int LW = TW + 8;         // LDS bytes used per row: x0-4 .. x0+TW+3
+constexpr int LP = 144;            // LDS row pitch in bytes (multiple of 8)
+constexpr int LR = TH + 4;         // LDS rows: y0-2 .. y0+TH+1
+constexpr int NT = 256;
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+template <bool DOWN, bool DERIV>
+__global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[LR * LP];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int slot = a.first + blockIdx.z;
+    const int w = a.src.w, h = a.src.h, pitch = a.src.pitch;
+    const uint8_t* __restrict__ src = a.src.img + (long long)slot * a.src.step;
+
+    // ---- stage the tile: coalesced dword loads of whole rows --------------------------------
+    for (int i = tid; i < LR * (LW / 4); i += NT) {
+        const int r = i / (LW / 4), c = i - r * (LW / 4);
+        const int y = reflect101(y0 - 2 + r, h);
+        const int x = x0 - 4 + 4 * c;
+        uint32_t v = 0;
+        if (x >= 0 && x < pitch) v = *reinterpret_cast<const uint32_t*>(src + (long long)y * pitch + x);
+        *reinterpret_cast<uint32_t*>(tile + r * LP + 4 * c) = v;
+    }
+    __syncthreads();
+
+    // ---- REFLECT_101 column patch (only tiles touching the left / right image edge) ----------
+    // LDS column of image column x is (x - x0 + 4).
+    const bool left_edge = (x0 == 0);
+    const bool right_edge = (x0 + TW + 4 > w);
+    if (left_edge || right_edge) {
+        for (int i = tid; i < LR * 5; i += NT) {
+            const int r = i / 5, k = i - r * 5;
+            int xd, xs;                        // destination / source image columns
+            if (k < 2) { if (!left_edge) continue; xd = -1 - k; xs = 1 + k; }
+            else       { if (!right_edge) continue; xd = w + (k - 2); xs = w - 2 - (k - 2); }
+            const int cd = xd - x0 + 4, cs = xs - x0 + 4;
+            if (cd >= 0 && cd < LW && cs >= 0 && cs < LW) tile[r * LP + cd] = tile[r * LP + cs];
+        }
+        __syncthreads();
+    }
+
+    // ---- Scharr derivatives of level l --------------------------------------------------------
+    if (DERIV) {
+        uint8_t* __restrict__ der = reinterpret_cast<uint8_t*>(a.src.der) + (long long)slot * a.src.dstep;
+#pragma unroll
+        for (int j = 0; j < (TW / 4) * TH / NT; ++j) {
+            const int i = tid + j * NT;
+            const int r = i / (TW / 4), c4 = i - r * (TW / 4);
+            const int x = x0 + 4 * c4, y = y0 + r;
+            if (x < w && y < h) {
+                // image columns x-1 .. x+4  ->  LDS bytes 4*c4+3 .. 4*c4+8 of rows r+1 .. r+3
+                int t0[6], t1[6];
+                const uint32_t* p0 = reinterpret_cast<const uint32_t*>(tile + (r + 1) * LP) + c4;
+                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(tile + (r + 2) * LP) + c4;
+                const uint32_t* p2 = reinterpret_cast<const uint32_t*>(tile + (r + 3) * LP) + c4;
+                const uint32_t u0 = p0[0], u1 = p0[1], u2 = p0[2];
+                const uint32_t m0 = p1[0], m1 = p1[1], m2 = p1[2];
+                const uint32_t d0 = p2[0], d1 = p2[1], d2 = p2[2];
+                auto col = [](uint32_t q0, uint32_t q1, uint32_t q2, int k) -> int {
+                    return k == 0 ? (int)(q0 >> 24) : k == 5 ? (int)(q2 & 0xff) : (int)((q1 >> (8 * (k - 1))) & 0xff);
+                };
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int up = col(u0, u1, u2, k), mid = col(m0, m1, m2, k), dn = col(d0, d1, d2, k);
+                    t0[k] = (up + dn) * 3 + mid * 10;
+                    t1[k] = dn - up;
+                }
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ix = t0[k + 2] - t0[k];
+                    const int iy = (t1[k] + t1[k + 2]) * 3 + t1[k + 1] * 10;
+                    o[k] = ((uint32_t)ix & 0xffffu) | ((uint32_t)iy << 16);
+                }
+                // zero the lanes' pixels beyond w so the pitch slack stays deterministic
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (x + k >= w) o[k] = 0;
+                uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+                *reinterpret_cast<uint4*>(der + (long long)y * a.src.dpitch + 4 * x) = v;
+            }
+        }
+    }
+
+    // ---- Gaussian pyrDown into level l+1 --------------------------------------------------------
+    if (DOWN) {
+        const int dw = a.dst.w, dh = a.dst.h;
+        uint8_t* __restrict__ dst = a.dst.img + (long long)slot * a.dst.step;
+        const int yi = tid / (TW / 8), g = tid - yi * (TW / 8);
+        const int X = x0 / 2 + 4 * g, Y = y0 / 2 + yi;
+        if (X < dw && Y < dh) {
+            int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                // image columns 2X-2 .. 2X+8  ->  LDS bytes 8g+2 .. 8g+12 of row 2*yi + j
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(tile + (2 * yi + j) * LP + 8 * g);
+                const uint64_t lo = q[0], hi = q[1];
+                int b[11];
+#pragma unroll
+                for (int m = 0; m < 11; ++m) {
+                    const int off = m + 2;
+                    b[m] = off < 8 ? (int)((lo >> (8 * off)) & 0xff) : (int)((hi >> (8 * (off - 8))) & 0xff);
+                }
+                const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int hs = b[2 * k + 2] * 6 + (b[2 * k + 1] + b[2 * k + 3]) * 4 + b[2 * k] + b[2 * k + 4];
+                    acc[k] += wj * hs;
+                }
+            }
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = (X + k < dw) ? (uint32_t)((acc[k] + 128) >> 8) : 0u;
+                o |= v << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(dst + (long long)Y * a.dst.pitch + X) = o;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, hipStream_t s)
+{
+    if (n_slots <= 0 || (!down && !deriv)) return hipSuccess;
+    dim3 grid((a.src.w + TW - 1) / TW, (a.src.h + TH - 1) / TH, n_slots);
+    dim3 block(NT);
+    if (down && deriv)      hipLaunchKernelGGL((pyr_level_kernel<true, true>),  grid, block, 0, s, a);
+    else if (down)          hipLaunchKernelGGL((pyr_level_kernel<true, false>), grid, block, 0, s, a);
+    else                    hipLaunchKernelGGL((pyr_level_kernel<false, true>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dr3

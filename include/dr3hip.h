@@ -1,0 +1,206 @@
+/*
+ * dr3hip.h -- C ABI of libdr3hip.so: the MI355X (gfx950) implementation of 3DR's dense hot path.
+ *
+ * The reference (kvmanohar22/3DR) has no plugin/FFI layer; its boundary for this path is a set of
+ * C++ call expressions into OpenCV and into its own utils::.  Each entry point below replaces one
+ * of them (reference file:line cited per function).  Conventions:
+ *   - plain pointers and sizes only; the caller owns every buffer it passes; nothing is freed or
+ *     retained by the callee beyond the call (device-resident objects are explicit handles);
+ *   - no C++ exceptions cross the boundary: every call returns 0 / a non-negative result on
+ *     success or a negative DR3HIP_E* code, with text in dr3hip_last_error(ctx);
+ *   - one dr3hip_ctx per GPU; a ctx is NOT thread-safe, distinct ctxs are;
+ *   - "host" calls are synchronous on return; "device" calls are enqueued on the ctx stream and
+ *     complete at dr3hip_sync().
+ * There is no CPU fallback: without a HIP device dr3hip_init fails with DR3HIP_ENODEV.
+ */
+#ifndef DR3HIP_H
+#define DR3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR3HIP_VERSION 100
+
+/* error codes */
+#define DR3HIP_OK        0
+#define DR3HIP_EINVAL   -1   /* bad argument                      */
+#define DR3HIP_ENODEV   -2   /* no usable HIP device              */
+#define DR3HIP_ENOMEM   -3   /* device or host allocation failed  */
+#define DR3HIP_EHIP     -4   /* HIP runtime error (see last_error) */
+#define DR3HIP_ERANGE   -5   /* parameter outside the supported range (e.g. window > 32) */
+
+/* pixel types (the three the reference passes to the warp calls, plus two for generality) */
+#define DR3HIP_8UC1   0      /* gray,  cv CV_8UC1                                  */
+#define DR3HIP_8UC3   1      /* BGR,   cv CV_8UC3  (src/stitch.cpp:73-74)          */
+#define DR3HIP_32FC4  2      /* BGRA f32, CV_32FC4 (src/panorama.cpp:192)          */
+#define DR3HIP_8UC4   3
+#define DR3HIP_32FC1  4
+
+/* flags */
+#define DR3HIP_LK_USE_INITIAL_FLOW    4   /* == cv::OPTFLOW_USE_INITIAL_FLOW (src/initialization.cpp:613) */
+#define DR3HIP_LK_GET_MIN_EIGENVALS   8   /* == cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+#define DR3HIP_WARP_INVERSE_MAP      16   /* == cv::WARP_INVERSE_MAP */
+#define DR3HIP_CRIT_COUNT             1   /* == cv::TermCriteria::COUNT */
+#define DR3HIP_CRIT_EPS               2   /* == cv::TermCriteria::EPS   */
+
+/* half-sample modes: src/utils.cpp:382-419 has three behaviours */
+#define DR3HIP_HALF_TRUNC       0   /* row-aligned (a+b+c+d)/4, the scalar/NEON arithmetic       */
+#define DR3HIP_HALF_SSE2        1   /* row-aligned avg(avg(a,c),avg(b,d)), the SSE2 arithmetic   */
+#define DR3HIP_HALF_REF_SCALAR  2   /* the scalar pointer walk as written: sheared for odd width */
+#define DR3HIP_HALF_REF_X86     3   /* what the reference executes on x86-64: SSE2 if cols%16==0 else REF_SCALAR */
+
+#define DR3HIP_MAX_LEVELS       8   /* pyramid levels 0..7 */
+#define DR3HIP_MAX_WIN         32   /* LK window side limit of this build */
+
+typedef struct dr3hip_ctx   dr3hip_ctx;
+typedef struct dr3hip_batch dr3hip_batch;
+
+/* Parameters of cv::calcOpticalFlowPyrLK as the reference passes them
+ * (src/initialization.cpp:593-599, :612-613).  Values are the caller's UN-clamped ones; the
+ * callee applies OpenCV's clamping (maxCount to [0,100], epsilon to [0,10] then squared). */
+typedef struct dr3hip_lk_params {
+    int    win_w, win_h;        /* cv::Size winSize          (reference: 30,30)          */
+    int    max_level;           /* maxLevel                  (reference: 4)              */
+    int    crit_type;           /* TermCriteria type         (reference: COUNT+EPS = 3)  */
+    int    max_iters;           /* TermCriteria maxCount     (reference: 1000)           */
+    double eps;                 /* TermCriteria epsilon      (reference: 1e-3)           */
+    int    flags;               /* DR3HIP_LK_*               (reference: USE_INITIAL_FLOW) */
+    double min_eig_threshold;   /* minEigThreshold           (OpenCV default 1e-4)       */
+} dr3hip_lk_params;
+
+/* fills *p with the literals of src/initialization.cpp:593-613 */
+void dr3hip_lk_params_reference(dr3hip_lk_params* p);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int         dr3hip_version(void);
+int         dr3hip_device_count(void);                       /* 0 when no GPU is visible */
+int         dr3hip_init(int device, dr3hip_ctx** out);
+void        dr3hip_destroy(dr3hip_ctx* ctx);
+const char* dr3hip_last_error(const dr3hip_ctx* ctx);        /* ctx may be NULL: last init error */
+int         dr3hip_sync(dr3hip_ctx* ctx);                    /* wait for the ctx stream */
+void*       dr3hip_stream(dr3hip_ctx* ctx);                  /* the hipStream_t kernels are launched on */
+
+/* device memory helpers so that a C/Go/Java caller needs no HIP headers */
+int dr3hip_malloc(dr3hip_ctx* ctx, size_t bytes, void** dptr);
+int dr3hip_free(dr3hip_ctx* ctx, void* dptr);
+int dr3hip_memcpy_h2d(dr3hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int dr3hip_memcpy_d2h(dr3hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int dr3hip_memset(dr3hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ---- host-buffer drop-in calls ------------------------------------------------------------ */
+
+/* Replaces cv::calcOpticalFlowPyrLK at src/initialization.cpp:608-613.
+ * prev/next: 8-bit gray, w x h, row strides in bytes.  prev_xy: n x (x,y) f32 (cv::Point2f AoS).
+ * next_xy: in/out, read as the initial guess when DR3HIP_LK_USE_INITIAL_FLOW.  status: n bytes
+ * (1 tracked / 0 lost).  err: n floats.  Returns the effective maxLevel (>=0) or <0. */
+int dr3hip_lk_track(dr3hip_ctx* ctx,
+                    const uint8_t* prev, const uint8_t* next, int w, int h,
+                    int prev_stride, int next_stride,
+                    const float* prev_xy, float* next_xy, int n,
+                    uint8_t* status, float* err, const dr3hip_lk_params* p);
+
+/* Effective maxLevel cv::buildOpticalFlowPyramid would return (no GPU work). */
+int dr3hip_lk_effective_max_level(int w, int h, int win_w, int win_h, int max_level);
+
+/* Replaces utils::create_img_pyramid (src/utils.cpp:421-430, called from src/frame.cpp:18).
+ * out_levels[0] is ignored (level 0 is the input, as in the reference); out_levels[1..n-1] are
+ * caller-allocated (w>>l) x (h>>l) planes with byte strides out_strides[l]. */
+int dr3hip_halfsample_pyramid(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                              int n_levels, int mode,
+                              uint8_t* const* out_levels, const int* out_strides);
+
+/* Replaces cv::warpPerspective at src/stitch.cpp:73-74 (8UC3) and src/panorama.cpp:192 (32FC4):
+ * INTER_LINEAR, BORDER_CONSTANT 0.  M is the row-major f32 3x3 the reference passes: the forward
+ * map src->dst, inverted internally unless DR3HIP_WARP_INVERSE_MAP.  Strides in bytes. */
+int dr3hip_warp_perspective(dr3hip_ctx* ctx,
+                            const void* src, int sw, int sh, int sstride, int type,
+                            void* dst, int dw, int dh, int dstride,
+                            const float M[9], int flags);
+
+/* Replaces cv::remap at src/utils.cpp:191 (CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT 0).
+ * mapx/mapy: dw x dh f32 planes, map_stride in bytes. */
+int dr3hip_remap_bilinear(dr3hip_ctx* ctx,
+                          const void* src, int sw, int sh, int sstride, int type,
+                          void* dst, int dw, int dh, int dstride,
+                          const float* mapx, const float* mapy, int map_stride);
+
+/* ---- device-resident batch API (BASELINE configs 2, 4, 5: frame streams / batched pairs) --- */
+
+/* A batch owns `capacity` frame slots of w x h gray frames on the device, each with its LK
+ * Gaussian pyramid (levels 0..L, L = effective maxLevel for the given window) and Scharr
+ * derivative pyramid.  All kernels take the frame index as a grid axis. */
+int  dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int max_level,
+                         int capacity, dr3hip_batch** out);
+void dr3hip_batch_destroy(dr3hip_batch* b);
+int  dr3hip_batch_levels(const dr3hip_batch* b);            /* L + 1 */
+size_t dr3hip_batch_bytes(const dr3hip_batch* b);           /* device bytes held */
+
+/* geometry + device pointers of one level's storage (slot s lives at ptr + s*slot_step) */
+typedef struct dr3hip_level_info {
+    int w, h;
+    int img_pitch;    size_t img_slot_step;   void* img;    /* u8  */
+    int der_pitch;    size_t der_slot_step;   void* der;    /* interleaved (Ix,Iy) int16, 4 B/px */
+} dr3hip_level_info;
+int  dr3hip_batch_level_info(const dr3hip_batch* b, int level, dr3hip_level_info* out);
+
+/* copy `count` host frames (each w x h, row stride `stride`, frame-to-frame step `frame_step`
+ * bytes) into slots first..first+count-1 (level 0).  Synchronous. */
+int  dr3hip_batch_upload(dr3hip_batch* b, int first, int count,
+                         const uint8_t* frames, int stride, size_t frame_step);
+/* copy one level of one slot back (tests): what = 0 image (u8, w*h), 1 derivative (int16 w*h*2) */
+int  dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void* host, int host_stride);
+
+/* Enqueue pyramid (+ derivative when with_deriv) construction for slots first..first+count-1.
+ * This is the "pyramid + gradient pass" graded against the HBM roofline. */
+int  dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv);
+
+/* Enqueue tracking of n_pairs frame pairs.  Pair i tracks slot prev_slot[i] -> next_slot[i]
+ * (device int arrays; NULL means prev = first_slot + i, next = first_slot + i + 1).
+ * prev_xy / next_xy: device, n_pairs x n_pts x 2 f32; status: n_pairs x n_pts u8; err: f32.
+ * iters: optional device int32 n_pairs x n_pts x (L+1) iteration counts (may be NULL).
+ * The prev slots must have been built with derivatives. */
+int  dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
+                        const int* d_prev_slot, const int* d_next_slot,
+                        const float* d_prev_xy, float* d_next_xy, int n_pts,
+                        uint8_t* d_status, float* d_err, int* d_iters,
+                        const dr3hip_lk_params* p);
+
+/* ---- device-resident warp (BASELINE config 3: panorama tiles) ----------------------------- */
+
+typedef struct dr3hip_warp_job {
+    const void* src; int sw, sh, sstride;     /* device pointers, strides in bytes */
+    void*       dst; int dw, dh, dstride;
+    float       M[9];                         /* as dr3hip_warp_perspective */
+} dr3hip_warp_job;
+
+/* Enqueue n_jobs warps of one pixel type in a single launch (job index is a grid axis). */
+int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs,
+                                  int type, int flags);
+/* Device-pointer remap (maps on device, strides in bytes). */
+int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
+                              const void* d_src, int sw, int sh, int sstride, int type,
+                              void* d_dst, int dw, int dh, int dstride,
+                              const float* d_mapx, const float* d_mapy, int map_stride);
+/* Device-pointer half-sampler for one level (src w x h -> dst (w/2) x (h/2)). */
+int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
+                          uint8_t* d_dst, int dstride, int mode);
+
+/* ---- timing ------------------------------------------------------------------------------- */
+/* hipEvent pair on the ctx stream (the stream the kernels run on). */
+int dr3hip_timer_start(dr3hip_ctx* ctx);
+int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on the stop event */
+/* Named accumulating kernel timers: when enabled (costs two events per launch group), every
+ * dr3hip_batch_build / _track / warp launch group is bracketed by events.  which: 0 pyr+grad,
+ * 1 lk track, 2 warp, 3 remap, 4 halfsample. */
+int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
+int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
+int dr3hip_profile_reset(dr3hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DR3HIP_H */

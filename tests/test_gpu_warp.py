@@ -1,0 +1,105 @@
+"""HIP bilinear backward warp / remap / half-sampler vs the oracle.
+Bar: 8-bit results bit-exact; f32 results bit-exact too (same operation order, no FMA), which is
+tighter than the 1 ULP north_star allows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_H(rng, scale=1.0):
+    ang = rng.uniform(-0.3, 0.3)
+    c, s = np.cos(ang), np.sin(ang)
+    return np.array([[c * rng.uniform(.8, 1.25), -s, rng.uniform(-10, 30) * scale],
+                     [s, c * rng.uniform(.8, 1.25), rng.uniform(-10, 30) * scale],
+                     [rng.uniform(-1e-3, 1e-3), rng.uniform(-1e-3, 1e-3), 1]], np.float32)
+
+
+def _eq(a, b):
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape,dtype", [((60, 80, 3), np.uint8), ((60, 80, 4), np.float32), ((60, 80), np.uint8),
+                                         ((61, 83, 4), np.uint8), ((45, 67), np.float32), ((480, 752, 3), np.uint8)])
+def test_warp_perspective_bit_exact(dr3, O, ctx, shape, dtype):
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    src = (rng.integers(0, 256, shape, dtype=np.uint8) if dtype == np.uint8
+           else (rng.random(shape, dtype=np.float32) * 255).astype(np.float32))
+    h, w = shape[:2]
+    for k in range(6):
+        M = _rand_H(rng, w / 80)
+        dsize = (int(w * 1.3) + k, int(h * 1.2) + 3 * k)
+        assert _eq(ctx.warpPerspective(src, M, dsize), O.warp_perspective(src, M, dsize)), k
+        assert _eq(ctx.warpPerspective(src, M, dsize, dr3.WARP_INVERSE_MAP),
+                   O.warp_perspective(src, M, dsize, O.WARP_INVERSE_MAP)), k
+
+
+def test_warp_identity_and_integer_translation(dr3, O, ctx):
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    assert np.array_equal(ctx.warpPerspective(src, np.eye(3, dtype=np.float32), (90, 70)), src)
+    M = np.array([[1, 0, 5], [0, 1, 3], [0, 0, 1]], np.float32)      # src/stitch.cpp:74: pure translation
+    d = ctx.warpPerspective(src, M, (100, 80))
+    assert np.array_equal(d[3:73, 5:95], src) and not d[:3].any() and not d[:, :5].any()
+    # sub-pixel translation (the reference's translate_top_left with fractional min_X/min_Y)
+    M = np.array([[1, 0, 5.37], [0, 1, 3.81], [0, 0, 1]], np.float32)
+    assert np.array_equal(ctx.warpPerspective(src, M, (100, 80)), O.warp_perspective(src, M, (100, 80)))
+
+
+def test_warp_small_and_degenerate(dr3, O, ctx):
+    """dst smaller than one 16x64 block, singular-ish / far-outside maps -> zeros like the oracle"""
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    for dsize in [(5, 3), (63, 15), (65, 17), (1, 1)]:
+        M = _rand_H(rng, 0.2)
+        assert np.array_equal(ctx.warpPerspective(src, M, dsize), O.warp_perspective(src, M, dsize)), dsize
+    M = np.array([[1, 0, 1e6], [0, 1, 0], [0, 0, 1]], np.float32)
+    assert not ctx.warpPerspective(src, M, (40, 30)).any()
+    M = np.array([[1, 0, 0], [0, 1, 0], [0.05, 0.01, 1]], np.float32)  # W crosses 0 inside the image
+    assert np.array_equal(ctx.warpPerspective(src, M, (80, 60)), O.warp_perspective(src, M, (80, 60)))
+
+
+def test_panorama_style_32fc4(dr3, O, synth, ctx):
+    """the src/panorama.cpp:178-192 form: (B,G,R,1.0) f32 image warped onto a larger canvas"""
+    tile = synth.panorama_tile(200, 150)
+    img = np.ones((150, 200, 4), np.float32)
+    img[..., :3] = tile.astype(np.float32)
+    M = synth.tile_homography(1, 200, 150)
+    got = ctx.warpPerspective(img, M, (360, 300))
+    want = O.warp_perspective(img, M, (360, 300))
+    assert _eq(got, want)
+    assert got[..., 3].max() == 1.0
+
+
+@pytest.mark.parametrize("shape,dtype", [((60, 80, 3), np.uint8), ((60, 80, 4), np.float32), ((50, 70), np.uint8)])
+def test_remap_bit_exact(dr3, O, ctx, shape, dtype):
+    rng = np.random.default_rng(11)
+    src = (rng.integers(0, 256, shape, dtype=np.uint8) if dtype == np.uint8 else rng.random(shape, dtype=np.float32))
+    h, w = shape[:2]
+    mx = rng.uniform(-3, w + 3, (57, 93)).astype(np.float32)
+    my = rng.uniform(-3, h + 3, (57, 93)).astype(np.float32)
+    mx[0, :8] = [0, 0.5, w - 1, w - 0.5, -1, -0.5, 1e9, -1e9]          # ties and saturating coordinates
+    assert _eq(ctx.remap(src, mx, my), O.remap(src, mx, my))
+
+
+def test_remap_spherical_maps(dr3, O, ctx, synth):
+    """utils::warp_spherical (src/utils.cpp:196-201): maps from the oracle's map generator"""
+    img = synth.panorama_tile(160, 120)
+    u, v = O.spherical_map(160, 120, 140.0)
+    assert np.array_equal(ctx.remap(img, u, v), O.remap(img, u, v))
+
+
+@pytest.mark.parametrize("w,h", [(1241, 376), (1240, 376), (1920, 1080), (64, 48), (33, 17), (101, 376)])
+@pytest.mark.parametrize("mode", ["HALF_TRUNC", "HALF_SSE2", "HALF_REF_SCALAR", "HALF_REF_X86"])
+def test_halfsample_pyramid_modes(dr3, O, ctx, w, h, mode):
+    rng = np.random.default_rng(w + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    n_levels = 3 if min(w, h) < 100 else 5
+    got = ctx.create_img_pyramid(img, n_levels, getattr(dr3, mode))
+    want = O.halfsample_pyramid(img, n_levels, getattr(O, mode))
+    assert len(got) == n_levels
+    for l in range(n_levels):
+        assert got[l].shape == want[l].shape == (h >> l, w >> l)
+        assert np.array_equal(got[l], want[l]), (mode, l)
