@@ -29,7 +29,7 @@ WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
-PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF = 0, 1, 2, 3, 4
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0 = 0, 1, 2, 3, 4, 5
 
 
 class Dr3HipError(RuntimeError):

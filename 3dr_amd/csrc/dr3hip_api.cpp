@@ -25,9 +25,10 @@ struct dr3hip_ctx {
     Buf stage[6];
     dr3hip_batch* lk_batch = nullptr;     // cached 2-slot batch behind dr3hip_lk_track
     bool prof = false;
-    double prof_ms[5] = {0, 0, 0, 0, 0};
-    int prof_n[5] = {0, 0, 0, 0, 0};
+    double prof_ms[DR3HIP_PROF_SLOTS] = {0};
+    int prof_n[DR3HIP_PROF_SLOTS] = {0};
     std::vector<ProfEvent> pending;
+    std::vector<hipEvent_t> ev_pool;      // recycled events: no hipEventCreate in the steady state
 };
 
 struct dr3hip_batch {
@@ -73,9 +74,12 @@ static int stage_reserve(dr3hip_ctx* ctx, int idx, size_t bytes)
 static void prof_begin(dr3hip_ctx* ctx, int which, ProfEvent& pe)
 {
     pe.which = -1;
-    if (!ctx->prof) return;
-    if (hipEventCreate(&pe.e0) != hipSuccess) return;
-    if (hipEventCreate(&pe.e1) != hipSuccess) { (void)hipEventDestroy(pe.e0); return; }
+    if (!ctx->prof || which < 0) return;
+    hipEvent_t* ev[2] = {&pe.e0, &pe.e1};
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->ev_pool.empty()) { *ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else if (hipEventCreate(ev[i]) != hipSuccess) { if (i) ctx->ev_pool.push_back(pe.e0); return; }
+    }
     pe.which = which;
     (void)hipEventRecord(pe.e0, ctx->stream);
 }
@@ -92,7 +96,7 @@ static void prof_drain(dr3hip_ctx* ctx)
         if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
             ctx->prof_ms[pe.which] += ms; ctx->prof_n[pe.which] += 1;
         }
-        (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1);
+        ctx->ev_pool.push_back(pe.e0); ctx->ev_pool.push_back(pe.e1);
     }
     ctx->pending.clear();
 }
@@ -151,6 +155,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     prof_drain(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
     for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -237,7 +242,7 @@ int dr3hip_profile_enable(dr3hip_ctx* ctx, int on)
 }
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n)
 {
-    if (!ctx || which < 0 || which >= 5) return DR3HIP_EINVAL;
+    if (!ctx || which < 0 || which >= DR3HIP_PROF_SLOTS) return DR3HIP_EINVAL;
     DeviceGuard g(ctx->device);
     prof_drain(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[which];
@@ -249,7 +254,7 @@ int dr3hip_profile_reset(dr3hip_ctx* ctx)
     if (!ctx) return DR3HIP_EINVAL;
     DeviceGuard g(ctx->device);
     prof_drain(ctx);
-    for (int i = 0; i < 5; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    for (int i = 0; i < DR3HIP_PROF_SLOTS; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
     return DR3HIP_OK;
 }
 
@@ -372,7 +377,7 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
     dr3hip_ctx* ctx = b->ctx;
     if (count == 0) return DR3HIP_OK;
     DeviceGuard g(ctx->device);
-    ProfEvent pe; prof_begin(ctx, 0, pe);
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PYR, pe);
     const int L = b->levels - 1;
     for (int l = 0; l <= L; ++l) {
         const bool down = l < L, deriv = with_deriv != 0;
@@ -383,7 +388,9 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             a.dst = down ? b->lv[l + 1] : b->lv[l];
             a.first = first + s0;
             const int n = count - s0 < 32768 ? count - s0 : 32768;
-            HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, ctx->stream));
+            ProfEvent p0; prof_begin(ctx, l == 0 ? DR3HIP_PROF_PYR_L0 : -1, p0);
+            HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream));
+            prof_end(ctx, p0);
         }
     }
     prof_end(ctx, pe);
@@ -430,7 +437,7 @@ int dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
     if (L < 0) return L;
     if (n_pairs == 0 || n_pts == 0) return L;
     DeviceGuard g(ctx->device);
-    ProfEvent pe; prof_begin(ctx, 1, pe);
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_LK, pe);
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {              // grid.y limit
         const int n = n_pairs - p0 < 32768 ? n_pairs - p0 : 32768;
         const size_t off = (size_t)p0 * n_pts;
@@ -507,7 +514,7 @@ int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, i
     a.src = d_src; a.w = w; a.h = h; a.sstride = sstride;
     a.dst = d_dst; a.ow = w / 2; a.oh = h / 2; a.dstride = dstride;
     a.mode = resolve_half_mode(mode, w);
-    ProfEvent pe; prof_begin(ctx, 4, pe);
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_HALF, pe);
     HIPCHK(ctx, launch_halfsample(a, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
@@ -603,7 +610,7 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
     // pageable source is copied out at enqueue time by hipMemcpyAsync, so hj may die at return
     HIPCHK(ctx, hipMemcpyAsync(ctx->stage[5].p, hj.data(), sizeof(WarpJobDev) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ProfEvent pe; prof_begin(ctx, 2, pe);
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_WARP, pe);
     HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p, n_jobs, max_dw, max_dh, type, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
@@ -647,7 +654,7 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx, const void* d_src, int sw, int sh
     a.src = (const uint8_t*)d_src; a.sw = sw; a.sh = sh; a.sstride = sstride;
     a.dst = (uint8_t*)d_dst; a.dw = dw; a.dh = dh; a.dstride = dstride;
     a.mapx = d_mapx; a.mapy = d_mapy; a.map_stride = map_stride;
-    ProfEvent pe; prof_begin(ctx, 3, pe);
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_REMAP, pe);
     HIPCHK(ctx, launch_remap(a, type, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;

@@ -69,7 +69,7 @@ struct HalfArgs {
 };
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
-hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, hipStream_t s);
+hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);

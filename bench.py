@@ -1,0 +1,412 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the dr3hip hot path on N MI355X GPUs of one node.
+
+Workload (BASELINE.json configs[1], "Single MI355X: KITTI-00 stream, 2000 corners/frame, 4-level
+pyr, 15x15 window, 30 LK iters"): a stream of synthetic 1241x376 gray frames.  One STEP = one batch
+of B new frames: the fused pyramid + Scharr-gradient pass for the B frames, then pyramidal LK
+tracking of the B consecutive frame pairs, 2000 points each.  Inputs (level-0 frames, points) are
+resident in HBM before the timed region starts.  value = tracked keypoints / s over the whole job.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank streams its own sequence
+(configs[3], weak scaling); the only collective is one RCCL broadcast of the camera intrinsics.
+The JSON line also carries the warp throughput of configs[2] (8 tiles 4000x3000), the HBM roofline
+of the dominant HBM-bound kernel measured with HIP events on the library's stream, and the CPU
+baseline (the oracle port, all host cores, bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+KITTI_W, KITTI_H = 1241, 376
+N_PTS, WIN, MAX_LEVEL, MAX_ITERS, EPS = 2000, 15, 3, 30, 0.01
+# tests/test_pipeline.cpp:62-64 -- the only state shared between GPUs (fx, fy, cx, cy, W, H)
+INTRINSICS = (718.856, 718.856, 607.1928, 185.2157, float(KITTI_W), float(KITTI_H))
+
+
+# ----------------------------------------------------------------------------------------------
+# distributed plumbing (torch.distributed: nccl == RCCL on ROCm; gloo for the CPU tests)
+# ----------------------------------------------------------------------------------------------
+class Dist:
+    def __init__(self, n_gpus, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.torch = None
+        self.device = None
+        self.pg = False
+        if self.world > 1 or backend:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            backend = backend or "nccl"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
+            else:
+                self.device = torch.device("cpu")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.pg = True
+
+    def barrier(self):
+        if self.pg:
+            self.dist.barrier()
+
+    def bcast_intrinsics(self, values):
+        """rank 0's (fx, fy, cx, cy, W, H) to every rank -- the path's only collective"""
+        if not self.pg:
+            return tuple(values)
+        t = self.torch.tensor(list(values) if self.rank == 0 else [0.0] * len(values),
+                              dtype=self.torch.float64, device=self.device)
+        self.dist.broadcast(t, src=0)
+        return tuple(float(v) for v in t.cpu().tolist())
+
+    def max_over_ranks(self, x):
+        if not self.pg:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if not self.pg:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.pg:
+            self.dist.destroy_process_group()
+            self.pg = False
+
+
+def timed_region(dist, step_fn, sync_fn, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides.
+    Returns the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    return dist.max_over_ranks(elapsed)
+
+
+def aggregate_rate(dist, units_this_rank, elapsed_max):
+    """whole-job units / s: sum of every rank's units over the slowest rank's time"""
+    return dist.sum_over_ranks(units_this_rank) / elapsed_max
+
+
+# ----------------------------------------------------------------------------------------------
+# algorithmic bytes
+# ----------------------------------------------------------------------------------------------
+def level_sizes(w, h, levels):
+    out = []
+    for _ in range(levels):
+        out.append((w, h))
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return out
+
+
+def pyr_grad_bytes_per_frame(w, h, levels):
+    """pyramid: read levels 0..L-1, write levels 1..L (1 B/px); gradient: read S, write 4 S"""
+    px = [a * b for a, b in level_sizes(w, h, levels)]
+    S = sum(px)
+    return sum(px[:-1]) + sum(px[1:]) + S + 4 * S
+
+
+def pyr_grad_level0_bytes_per_frame(w, h):
+    """the level-0 launch alone: pyrDown reads W0H0 and writes W1H1, Scharr reads W0H0, writes 4 W0H0"""
+    p0 = w * h
+    p1 = ((w + 1) // 2) * ((h + 1) // 2)
+    return p0 + p1 + p0 + 4 * p0
+
+
+def lk_unique_bytes_per_pair(n, levels, win):
+    return n * levels * (win + 1) ** 2 * 6 + 21 * n
+
+
+# ----------------------------------------------------------------------------------------------
+def stream_frames(synth, n_slots, w, h, period=9):
+    """ping-pong over `period` distinct analytic frames: consecutive slots always differ by one
+    motion step (forward or backward), like consecutive frames of a sequence"""
+    base, _ = synth.frame_stream(period, w, h)
+    seq = list(range(period)) + list(range(period - 2, 0, -1))
+    return [base[seq[i % len(seq)]] for i in range(n_slots)], base
+
+
+def cheap_tile(synth, w, h):
+    """4000x3000x3 u8 tile: low-res analytic texture upsampled + deterministic fine pattern
+    (content does not influence warp timing; the full analytic generator would take minutes)"""
+    f = 8
+    low = synth.Texture(w // f, h // f, channels=3).render()
+    big = np.repeat(np.repeat(low, f, axis=0), f, axis=1)[:h, :w].astype(np.int16)
+    yy, xx = np.mgrid[0:h, 0:w]
+    big += (((xx * 7 + yy * 13) & 15) - 8)[..., None].astype(np.int16)
+    return np.clip(big, 0, 255).astype(np.uint8)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per step and per GPU")
+    ap.add_argument("--no-warp", action="store_true", help="skip the configs[2] warp leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args(argv)
+
+    # torch first: its bundled libamdhip64 and ours share one SONAME, so whichever is loaded first
+    # serves both; loading torch's first keeps a single HIP runtime in the process.
+    import torch
+    dist = Dist(args.gpus, backend="nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    dr3 = importlib.import_module("3dr_amd")
+    synth = importlib.import_module("3dr_amd.synth")
+
+    fx, fy, cx, cy, Wf, Hf = dist.bcast_intrinsics(INTRINSICS)
+    W, H = int(Wf), int(Hf)
+    B = args.batch
+    ctx = dr3.Context(dist.local_rank)
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    # ---- resident inputs ------------------------------------------------------------------------
+    frames, base = stream_frames(synth, B + 1, W, H)
+    batch = dr3.FrameBatch(ctx, W, H, win=(WIN, WIN), max_level=MAX_LEVEL, capacity=B + 1)
+    levels = batch.levels
+    for s0 in range(0, B + 1, 64):
+        batch.upload(s0, np.stack(frames[s0:s0 + 64]))
+    pts = synth.grid_points(W, H, 15, n=N_PTS)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (B, N_PTS, 2)), np.float32)
+    d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+    d_st, d_err = ctx.alloc(B * N_PTS), ctx.alloc(B * N_PTS * 4)
+    params = dr3.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
+    batch.build(0, 1, True)          # the frame carried over from the previous batch of the stream
+
+    def step():
+        batch.build(1, B, True)                                  # pyramid + gradient pass, B new frames
+        batch.track(B, 0, d_prev, d_next, N_PTS, d_st, d_err, params)   # B pairs x 2000 points
+
+    # ---- timed region --------------------------------------------------------------------------
+    ctx.profile_enable(True)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.profile_reset()
+    elapsed = timed_region(dist, step, sync, args.steps, 0)
+    kps = aggregate_rate(dist, B * N_PTS * args.steps, elapsed)
+    ms_l0, n_l0 = ctx.profile_read(dr3.PROF_PYR_L0)
+    ms_pass, n_pass = ctx.profile_read(dr3.PROF_PYR)
+    ms_lk, n_lk = ctx.profile_read(dr3.PROF_LK)
+    ctx.profile_enable(False)
+
+    # ---- result check against the oracle (rank 0, pair 0) -------------------------------------------
+    verified = None
+    tracked_frac = float(d_st.download((B, N_PTS), np.uint8).mean())
+    if dist.rank == 0:
+        from oracle import oracle as O
+        po = O.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
+        o_xy, o_st, o_err, _ = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_WAVE64)
+        g_xy = d_next.download((B, N_PTS, 2), np.float32)[0]
+        g_st = d_st.download((B, N_PTS), np.uint8)[0]
+        verified = bool(np.array_equal(g_xy, o_xy) and np.array_equal(g_st, o_st))
+
+    # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------
+    warp = None
+    if not args.no_warp:
+        warp = warp_leg(dist, ctx, dr3, synth, sync, steps=max(3, min(args.steps, 10)))
+
+    # ---- CPU baseline (rank 0 only, bounded sample) -----------------------------------------------------
+    cpu = None
+    if dist.rank == 0 and not args.no_cpu and dist.world == 1:
+        cpu = cpu_baseline(frames, pts, args.cpu_seconds, warp is not None, synth)
+
+    if dist.rank == 0:
+        b_l0 = pyr_grad_level0_bytes_per_frame(W, H) * B
+        b_pass = pyr_grad_bytes_per_frame(W, H, levels) * B
+        l0_ms = ms_l0 / max(n_l0, 1)
+        pass_ms = ms_pass / max(n_pass, 1)
+        lk_ms = ms_lk / max(n_lk, 1)
+        ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
+        ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
+        out = {
+            "metric": "tracked_keypoints_per_sec",
+            "value": kps,
+            "unit": "keypoints/s",
+            "n_gpus": dist.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: KITTI-00-shaped stream 1241x376 u8, 2000 corners/frame, "
+                                   "4-level pyr (maxLevel 3), 15x15 window, 30 LK iters (COUNT+EPS 0.01)",
+                       "frame_pairs_per_step_per_gpu": B, "points_per_pair": N_PTS,
+                       "sequences": dist.world, "parallelism": "one sequence per GPU, no data-path collective",
+                       "intrinsics_bcast": [fx, fy, cx, cy, W, H]},
+            "frames_per_sec": kps / N_PTS,
+            "tracked_fraction": tracked_frac,
+            "verified_vs_oracle": verified,
+            "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)",
+                         "bound": "hbm", "achieved": ach_l0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_l0, "avg_launch_ms": l0_ms, "launches": n_l0},
+            "roofline_pyr_grad_pass": {"kernel": "all %d level launches of one pyramid+gradient pass" % levels,
+                                       "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": ach_pass / HBM_PEAK_GBPS, "traffic": None,
+                                       "algorithmic_bytes_per_pass": b_pass, "avg_pass_ms": pass_ms},
+            "lk_kernel": {"kernel": "lk_track_kernel<1>", "avg_launch_ms": lk_ms,
+                          "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
+                          "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
+                          "note": "latency/issue-bound, not HBM-bound (SURVEY 8d): no roofline fraction claimed"},
+            "warp": warp,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+
+    for d in (d_prev, d_next, d_st, d_err):
+        d.free()
+    batch.close()
+    ctx.close()
+    dist.close()
+    return 0
+
+
+def warp_leg(dist, ctx, dr3, synth, sync, steps):
+    """configs[2]: 8 tiles 4000x3000, one homography per tile evaluated per pixel, bilinear, border 0.
+    Run as 8UC3 (6 B/px) and as the reference's real 32FC4 form (32 B/px, src/panorama.cpp:178-192)."""
+    TW_, TH_, NT_ = 4000, 3000, 8
+    tile = cheap_tile(synth, TW_, TH_)
+    res = {}
+    for name, typ, esz in (("8uc3", dr3.T_8UC3, 3), ("32fc4", dr3.T_32FC4, 16)):
+        if typ == dr3.T_32FC4:
+            host = np.ones((TH_, TW_, 4), np.float32)
+            host[..., :3] = tile
+        else:
+            host = tile
+        stride = TW_ * esz
+        srcs = [ctx.to_device(host) for _ in range(NT_)]
+        dsts = [ctx.alloc(TH_ * stride) for _ in range(NT_)]
+        jobs = []
+        for i in range(NT_):
+            M = synth.tile_homography(i, TW_, TH_)
+            M[0, 2] -= 60.0; M[1, 2] -= 60.0            # keep most of each tile inside its canvas
+            jobs.append(dict(src=srcs[i].ptr, sw=TW_, sh=TH_, sstride=stride,
+                             dst=dsts[i].ptr, dw=TW_, dh=TH_, dstride=stride, M=M))
+        ctx.profile_enable(True)
+        dr3.warp_batch(ctx, jobs, typ)                   # warm-up
+        sync()
+        ctx.profile_reset()
+        el = timed_region(dist, lambda: dr3.warp_batch(ctx, jobs, typ), sync, steps, 0)
+        ms, n = ctx.profile_read(dr3.PROF_WARP)
+        ctx.profile_enable(False)
+        mpix = aggregate_rate(dist, NT_ * TW_ * TH_ * steps / 1e6, el)
+        k_ms = ms / max(n, 1)
+        alg = NT_ * TW_ * TH_ * 2 * esz                  # esz read + esz written per dst pixel
+        res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms,
+                     "roofline": {"kernel": "warp_perspective_kernel<%s>" % name.upper(), "bound": "hbm",
+                                  "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                                  "algorithmic_bytes_per_launch": alg}}
+        for d in srcs + dsts:
+            d.free()
+    res["workload"] = "configs[2]: 8 tiles 4000x3000, per-pixel homography, bilinear, border 0"
+    return res
+
+
+def host_cores():
+    """usable host cores: the affinity mask capped by the cgroup CPU quota (a container may see 256
+    CPUs in its mask while being allowed 16 cores' worth of time; oversubscribing OpenMP on that
+    makes the baseline meaninglessly slow)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames, pts, seconds, with_warp, synth):
+    """the oracle (a port of the reference's OpenCV calls) on all host cores, bounded sample.
+    Mirrors the reference's call shape: one calcOpticalFlowPyrLK(prev, next) per pair, which
+    rebuilds both Gaussian pyramids and the derivative pyramid each call (src/initialization.cpp:608)."""
+    from oracle import oracle as O
+    cores = host_cores()
+    po = O.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
+    O.lk_track(frames[0], frames[1], pts, None, po, n_threads=cores)          # warm-up
+    t0 = time.perf_counter()
+    n_pairs = 0
+    while True:
+        i = n_pairs % (len(frames) - 1)
+        O.lk_track(frames[i], frames[i + 1], pts, None, po, n_threads=cores)
+        n_pairs += 1
+        if time.perf_counter() - t0 > seconds or n_pairs >= 4096:
+            break
+    el = time.perf_counter() - t0
+    out = {"value": n_pairs * len(pts) / el, "unit": "keypoints/s", "cores": cores, "kind": "port",
+           "cpu_model": cpu_model(),
+           "sample": "%d frame pairs x %d points of the same stream, oracle dr3o_lk_track (pyramids + Scharr + "
+                     "tracker per pair, OpenMP over rows/points), %.1f s" % (n_pairs, len(pts), el)}
+    if with_warp:
+        tile = cheap_tile(synth, 4000, 3000)
+        M = synth.tile_homography(0, 4000, 3000)
+        O.warp_perspective(tile, M, (4000, 3000), n_threads=cores)      # warm-up (page faults, threads)
+        t0 = time.perf_counter()
+        n_t = 0
+        while n_t < 64:
+            O.warp_perspective(tile, M, (4000, 3000), n_threads=cores)
+            n_t += 1
+            if time.perf_counter() - t0 > max(3.0, seconds / 4):
+                break
+        elw = time.perf_counter() - t0
+        out["warp_8uc3_mpix_per_s"] = 12.0 * n_t / elw
+        out["warp_sample"] = "%d x one 4000x3000 8UC3 tile, oracle dr3o_warp_perspective, %.2f s" % (n_t, elw)
+    return out
+
+
+if __name__ == "__main__":
+    sys.exit(main())

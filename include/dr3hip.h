@@ -193,9 +193,15 @@ int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, i
 /* hipEvent pair on the ctx stream (the stream the kernels run on). */
 int dr3hip_timer_start(dr3hip_ctx* ctx);
 int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on the stop event */
-/* Named accumulating kernel timers: when enabled (costs two events per launch group), every
- * dr3hip_batch_build / _track / warp launch group is bracketed by events.  which: 0 pyr+grad,
- * 1 lk track, 2 warp, 3 remap, 4 halfsample. */
+/* Named accumulating kernel timers: when enabled (two recycled events per bracket), every launch
+ * group is bracketed by hipEvents on the ctx stream and the elapsed times accumulate per slot. */
+#define DR3HIP_PROF_PYR     0   /* whole pyramid + gradient pass of one dr3hip_batch_build (all levels) */
+#define DR3HIP_PROF_LK      1   /* dr3hip_batch_track launch                                           */
+#define DR3HIP_PROF_WARP    2   /* warp_perspective launch                                             */
+#define DR3HIP_PROF_REMAP   3
+#define DR3HIP_PROF_HALF    4
+#define DR3HIP_PROF_PYR_L0  5   /* the level-0 fused pyrDown+Scharr kernel alone (dominant HBM kernel) */
+#define DR3HIP_PROF_SLOTS   6
 int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
 int dr3hip_profile_reset(dr3hip_ctx* ctx);
