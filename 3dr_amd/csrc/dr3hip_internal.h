@@ -34,6 +34,8 @@ struct LKArgs {
     int win_w, win_h;
     int rpr;               // runs (of 4 taps) per window row = ceil(win_w / 4)
     int n_items;           // rpr * win_h lane-items per window
+    int rwd, rh, lpd;      // staged J region: dwords per row, rows, LDS row pitch in dwords (odd)
+    int cw_shift;          // log2 of the staging column count (power of two >= rwd)
     int max_count;         // clamped iteration limit
     int flags;
     int n_pts;

@@ -2,24 +2,30 @@
 // cv::calcOpticalFlowPyrLK as called at reference src/initialization.cpp:608-613
 // (LKTrackerInvoker).
 //
-// Mapping: ONE wave64 per (frame pair, point); all pyramid levels run coarse -> fine inside the
-// wave, the running estimate never leaves registers.  The window is cut into lane-items: item
-// q = ty * rpr + r covers the 4 taps (ty, 4r .. 4r+3); lane = q % 64, pass = q / 64 (NPASS passes,
-// template parameter so the patch lives in statically indexed VGPRs).  Per level each lane
-//   1. extracts its taps of the template patch (I, Ix, Iy: 14-bit fixed-point bilinear, integer
-//      exact) once and keeps them in registers,
-//   2. per Gauss-Newton iteration fetches the matching J taps (two aligned dword loads per row,
-//      funnel-shifted), forms the mismatch and the two b sums,
-//   3. reduces the f32 sums across the wave with DPP adds (no LDS), solves the 2x2 system
-//      redundantly in every lane and tests the (wave-uniform) exit conditions.
+// Mapping: ONE wave64 per (frame pair, point), one wave per workgroup; all pyramid levels run
+// coarse -> fine inside the wave, the running estimate never leaves registers.  The window is cut
+// into lane-items: item q = ty * rpr + r covers the 4 taps (ty, 4r .. 4r+3); lane = q % 64,
+// pass = q / 64 (NPASS passes, template parameter so the patch lives in statically indexed VGPRs).
+// Per level the wave
+//   1. stages the J search region (window + RM px margin, REFLECT_101 already applied) from
+//      global memory into its private LDS slice with aligned dword loads -- ONE global round trip
+//      per level instead of one per Gauss-Newton iteration;
+//   2. extracts its taps of the template patch (I, Ix, Iy: 14-bit fixed-point bilinear, integer
+//      exact) once and keeps them in registers;
+//   3. iterates out of LDS: two ds_read2_b32 per lane-item, v_perm_b32 + v_dot2_u32_u16 for the
+//      bilinear J taps, v_mul_i32_i24 for mismatch x gradient, f32 accumulation;
+//   4. reduces the two f32 sums across the wave with one v_permlane32_swap + DPP adds (no LDS),
+//      solves the 2x2 system redundantly in every lane and tests the wave-uniform exit conditions.
+// If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged
+// around it, so results never depend on the margin.
 // Border handling: OpenCV pads every level by winSize (REFLECT_101 for images, zeros for
-// derivatives); here windows that leave the image take a wave-uniform slow path that reflects
-// indices instead, so no padded copy of the pyramid is ever written to HBM.
+// derivatives); here indices are reflected while staging / extracting, so no padded copy of the
+// pyramid is ever written to HBM.
 //
 // Float summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64):
-// lane-local sequential over (pass, tap k), then an xor butterfly over lanes with strides
-// 1,2,4,8,16,32.  The DPP sequence below (quad_perm, quad_perm, row_half_mirror, row_mirror,
-// row_bcast15, row_bcast31, readlane 63) produces exactly that tree.  No FMA contraction
+// lane-local sequential over (pass, tap k) into p[lane]; a[l] = p[l] + p[l+32] (l < 32); inside
+// each row of 16 lanes an xor butterfly with strides 1,2,4,8 gives the row sums R0, R1; the total
+// is R1 + R0.  wave_sum2 produces exactly that tree for TWO sums at once.  No FMA contraction
 // (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
 #include "dr3hip_internal.h"
 
@@ -27,6 +33,10 @@ namespace dr3 {
 namespace {
 
 constexpr int W_BITS = 14;
+constexpr int RM = 4;              // search margin (px) of the staged J region
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int reflect101(int p, int n)
 {
@@ -34,81 +44,151 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// ---- wave64 all-reduce of one f32 ----------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v)
+// ---- wave64 reduction of two f32 sums at once ---------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v)
 {
-#if defined(DR3_REDUCE_SHFL)
-    v += __shfl_xor(v, 1);  v += __shfl_xor(v, 2);  v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);  v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-    return v;
-#else
-    // symmetric exchanges inside each row of 16 lanes: after these every lane of a row holds the
-    // row sum, associated exactly like xor strides 1,2,4,8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
-    // rows 1,3 += last lane of rows 0,2 ; rows 2,3 += last lane of row 1  (old = 0 for masked rows)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false)); // row_bcast15
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false)); // row_bcast31
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-#endif
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-struct Weights { int w00, w01, w10, w11; };
+__device__ __forceinline__ void wave_sum2(float a, float b, float& ra, float& rb)
+{
+    // lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    v += dpp_xchg<0xB1>(v);     // quad_perm [1,0,3,2]   (xor 1)
+    v += dpp_xchg<0x4E>(v);     // quad_perm [2,3,0,1]   (xor 2)
+    v += dpp_xchg<0x141>(v);    // row_half_mirror       (= xor 4 once quads are uniform)
+    v += dpp_xchg<0x140>(v);    // row_mirror            (= xor 8 once half-rows are uniform)
+    // rows 1 and 3 += last lane of rows 0 and 2 (masked rows read old = 0)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    ra = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    rb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// ---- fixed-point bilinear blends ------------------------------------------------------------------
+// 14-bit weights packed for the dot2 instructions: (w00 | w01 << 16), (w10 | w11 << 16)
+struct Weights { uint32_t w01, w23; };
 
 __device__ __forceinline__ Weights make_weights(float a, float b)
 {
+    const int w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    const int w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+    const int w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+    const int w11 = (1 << W_BITS) - w00 - w01 - w10;
     Weights W;
-    W.w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    W.w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
-    W.w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
-    W.w11 = (1 << W_BITS) - W.w00 - W.w01 - W.w10;
+    W.w01 = (uint32_t)w00 | ((uint32_t)w01 << 16);
+    W.w23 = (uint32_t)w10 | ((uint32_t)w11 << 16);
     return W;
 }
 
-// 5 consecutive bytes of two image rows starting at (x, y) -> r0, r1 (byte k in bits 8k..8k+7).
-// fast: whole window inside the image, aligned dword pairs + 64-bit funnel shift.
-__device__ __forceinline__ void load_rows_fast(const uint8_t* __restrict__ img, int pitch, int x, int y,
-                                               uint64_t& r0, uint64_t& r1)
+// Two image rows as aligned 8-byte windows (lo, hi dwords); tap k uses bytes o+k, o+k+1.
+struct Rows { uint32_t lo0, hi0, lo1, hi1; };
+
+// v_perm_b32 selector picking bytes (o+k, o+k+1) of {hi,lo} into the two u16 halves (0x0c = zero)
+__device__ __forceinline__ uint32_t tap_sel(int o, int k)
+{
+    return 0x0c000c00u | (uint32_t)(o + k) | ((uint32_t)(o + k + 1) << 16);
+}
+
+// CV_DESCALE(I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11, W_BITS - 5): two perms + two dot2
+__device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weights& W)
+{
+    const uint32_t p0 = __builtin_amdgcn_perm(r.hi0, r.lo0, sel);
+    const uint32_t p1 = __builtin_amdgcn_perm(r.hi1, r.lo1, sel);
+    uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), __builtin_bit_cast(u16x2, W.w01),
+                                        1u << (W_BITS - 5 - 1), false);
+    v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), __builtin_bit_cast(u16x2, W.w23), v, false);
+    return (int)(v >> (W_BITS - 5));
+}
+
+// CV_DESCALE(d00*iw00 + d01*iw01 + d10*iw10 + d11*iw11, W_BITS) on one int16 channel of the
+// interleaved derivative; a0,a1 = dwords (Ix | Iy << 16) of columns k, k+1 of row y, b0,b1 of row y+1
+template <uint32_t SEL>
+__device__ __forceinline__ int bilin_s16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const Weights& W)
+{
+    const uint32_t p0 = __builtin_amdgcn_perm(a1, a0, SEL);
+    const uint32_t p1 = __builtin_amdgcn_perm(b1, b0, SEL);
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 1), false);
+    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, false);
+    return v >> W_BITS;
+}
+
+// ---- global loads of the template (I) rows ----------------------------------------------------------
+// fast: whole window inside the image -> aligned dword pairs, byte offset o = x & 3 (wave-uniform)
+__device__ __forceinline__ Rows load_rows_fast(const uint8_t* __restrict__ img, int pitch, int x, int y)
 {
     const uint8_t* p = img + (long long)y * pitch + (x & ~3);
-    const int sh = (x & 3) * 8;
-    const uint32_t a0 = *reinterpret_cast<const uint32_t*>(p);
-    const uint32_t a1 = *reinterpret_cast<const uint32_t*>(p + 4);
-    const uint32_t b0 = *reinterpret_cast<const uint32_t*>(p + pitch);
-    const uint32_t b1 = *reinterpret_cast<const uint32_t*>(p + pitch + 4);
-    r0 = (((uint64_t)a1 << 32) | a0) >> sh;
-    r1 = (((uint64_t)b1 << 32) | b0) >> sh;
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    const uint2 b = *reinterpret_cast<const uint2*>(p + pitch);
+    Rows r; r.lo0 = a.x; r.hi0 = a.y; r.lo1 = b.x; r.hi1 = b.y;
+    return r;
 }
-// slow: REFLECT_101 index per byte (window crosses the image border)
-__device__ __forceinline__ void load_rows_slow(const uint8_t* __restrict__ img, int pitch, int w, int h,
-                                               int x, int y, uint64_t& r0, uint64_t& r1)
+// slow: REFLECT_101 index per byte (window crosses the image border); bytes packed at offset 0
+__device__ __forceinline__ Rows load_rows_slow(const uint8_t* __restrict__ img, int pitch, int w, int h, int x, int y)
 {
     const uint8_t* p0 = img + (long long)reflect101(y, h) * pitch;
     const uint8_t* p1 = img + (long long)reflect101(y + 1, h) * pitch;
-    r0 = 0; r1 = 0;
+    Rows r; r.lo0 = 0; r.lo1 = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int xr = reflect101(x + k, w);
-        r0 |= (uint64_t)p0[xr] << (8 * k);
-        r1 |= (uint64_t)p1[xr] << (8 * k);
+        r.lo0 |= (uint32_t)p0[xr] << (8 * k);
+        r.lo1 |= (uint32_t)p1[xr] << (8 * k);
     }
+    const int x4 = reflect101(x + 4, w);
+    r.hi0 = p0[x4]; r.hi1 = p1[x4];
+    return r;
 }
 
-__device__ __forceinline__ int byte_of(uint64_t r, int k) { return (int)((r >> (8 * k)) & 0xff); }
+// ---- J search region in LDS --------------------------------------------------------------------------
+struct Region { int x0, y0; };       // image coordinates of LDS (row 0, byte 0); x0 is a multiple of 4
 
-__device__ __forceinline__ int bilin_u8(uint64_t r0, uint64_t r1, int k, const Weights& W)
+// Stage rows [cy-RM, cy-RM+rh) x aligned byte columns [x0, x0+4*rwd) of level L of frame J.
+__device__ __forceinline__ Region stage_region(const uint8_t* __restrict__ J, const LevelDev& L, int inx, int iny,
+                                               uint32_t* __restrict__ lds, int rwd, int rh, int lpd, int cw_shift, int lane)
 {
-    // CV_DESCALE(I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11, W_BITS - 5)
-    const int v = byte_of(r0, k) * W.w00 + byte_of(r0, k + 1) * W.w01 +
-                  byte_of(r1, k) * W.w10 + byte_of(r1, k + 1) * W.w11;
-    return (v + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+    Region R;
+    R.x0 = (inx - RM) & ~3;
+    R.y0 = iny - RM;
+    // lanes form a (64 >> cw_shift) x (1 << cw_shift) grid over (rows, dword columns): no division
+    const int c = lane & ((1 << cw_shift) - 1);
+    for (int r = lane >> cw_shift; r < rh; r += 64 >> cw_shift) {
+        if (c >= rwd) continue;
+        const uint8_t* row = J + (long long)reflect101(R.y0 + r, L.h) * L.pitch;
+        const int x = R.x0 + 4 * c;
+        uint32_t v;
+        if (x >= 0 && x + 3 < L.w) {
+            v = *reinterpret_cast<const uint32_t*>(row + x);
+        } else {
+            v = (uint32_t)row[reflect101(x, L.w)] | ((uint32_t)row[reflect101(x + 1, L.w)] << 8) |
+                ((uint32_t)row[reflect101(x + 2, L.w)] << 16) | ((uint32_t)row[reflect101(x + 3, L.w)] << 24);
+        }
+        lds[r * lpd + c] = v;
+    }
+    __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS ops of a wave are ordered
+    return R;
+}
+
+__device__ __forceinline__ bool region_covers(const Region& R, int inx, int iny, int rpr, int win_h, int rwd, int rh)
+{
+    const int xb = inx & ~3;
+    return xb >= R.x0 && xb + 4 * rpr + 4 <= R.x0 + 4 * rwd && iny >= R.y0 && iny + win_h + 1 <= R.y0 + rh;
+}
+
+// base = wave-uniform dword offset of (inx & ~3, iny) in the region; loff = the lane-item's own offset
+__device__ __forceinline__ Rows lds_rows(const uint32_t* __restrict__ lds, int lpd, int base, int loff)
+{
+    const uint32_t* p = lds + base + loff;
+    Rows r; r.lo0 = p[0]; r.hi0 = p[1]; r.lo1 = p[lpd]; r.hi1 = p[lpd + 1];
+    return r;
 }
 
 template <int NPASS>
 __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
     const int lane = threadIdx.x;
     const int pt = blockIdx.x, pair = blockIdx.y;
     const long long pidx = (long long)pair * a.n_pts + pt;
@@ -118,19 +198,21 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
     const float ppx = a.prev_xy[2 * pidx], ppy = a.prev_xy[2 * pidx + 1];
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
-    const int win_w = a.win_w, win_h = a.win_h;
+    const int win_w = a.win_w, win_h = a.win_h, rpr = a.rpr;
+    const int rwd = a.rwd, rh = a.rh, lpd = a.lpd;
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
 
     // lane-item geometry (fixed for the whole kernel)
-    int itx[NPASS], ity[NPASS];
+    int itx[NPASS], ity[NPASS], loff[NPASS];   // loff: lane's dword offset inside the staged region
     bool ivalid[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int q = p * 64 + lane;
         ivalid[p] = q < a.n_items;
-        ity[p] = q / a.rpr;
-        itx[p] = 4 * (q - ity[p] * a.rpr);
+        ity[p] = q / rpr;
+        itx[p] = 4 * (q - ity[p] * rpr);
+        loff[p] = ity[p] * lpd + (itx[p] >> 2);
     }
 
     int   status = 1;
@@ -163,6 +245,19 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             continue;
         }
 
+        // ---- stage the J search region around the starting estimate (overlaps the I loads) ------
+        const uint8_t* __restrict__ J = L.img + (long long)ns * L.step;
+        Region R;
+        {
+            const int sx = __builtin_amdgcn_readfirstlane((int)floorf(cx - half_x));
+            const int sy = __builtin_amdgcn_readfirstlane((int)floorf(cy - half_y));
+            // a start outside the level is rejected by the first iteration's bounds test; clamp the
+            // staging centre so the (unused) region stays addressable
+            const int cxs = sx < -win_w ? -win_w : (sx >= L.w ? L.w - 1 : sx);
+            const int cys = sy < -win_h ? -win_h : (sy >= L.h ? L.h - 1 : sy);
+            R = stage_region(J, L, cxs, cys, lds, rwd, rh, lpd, a.cw_shift, lane);
+        }
+
         // ---- template patch + structure tensor ------------------------------------------------
         float A11, A12, A22;
         {
@@ -170,6 +265,8 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             const uint8_t* __restrict__ I = L.img + (long long)ps * L.step;
             const uint8_t* __restrict__ dI = reinterpret_cast<const uint8_t*>(L.der) + (long long)ps * L.dstep;
             const bool inside = ipx >= 0 && ipy >= 0 && ipx + win_w < L.w && ipy + win_h < L.h;
+            const int o = inside ? (ipx & 3) : 0;
+            const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
             float s11 = 0.f, s12 = 0.f, s22 = 0.f;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
@@ -177,47 +274,46 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
                 for (int k = 0; k < 4; ++k) { Iv[p][k] = 0; Ix[p][k] = 0; Iy[p][k] = 0; }
                 if (ivalid[p]) {
                     const int x = ipx + itx[p], y = ipy + ity[p];
-                    uint64_t r0, r1;
+                    Rows r;
                     uint32_t d0[5], d1[5];     // packed (Ix | Iy<<16) of rows y, y+1, columns x..x+4
                     if (inside) {
-                        load_rows_fast(I, L.pitch, x, y, r0, r1);
+                        r = load_rows_fast(I, L.pitch, x, y);
                         const uint32_t* q0 = reinterpret_cast<const uint32_t*>(dI + (long long)y * L.dpitch) + x;
                         const uint32_t* q1 = reinterpret_cast<const uint32_t*>(dI + (long long)(y + 1) * L.dpitch) + x;
 #pragma unroll
                         for (int k = 0; k < 5; ++k) { d0[k] = q0[k]; d1[k] = q1[k]; }
                     } else {
-                        load_rows_slow(I, L.pitch, L.w, L.h, x, y, r0, r1);
+                        r = load_rows_slow(I, L.pitch, L.w, L.h, x, y);
+                        const bool v0 = y >= 0 && y < L.h, v1 = y + 1 >= 0 && y + 1 < L.h;
+                        const uint32_t* q0 = reinterpret_cast<const uint32_t*>(dI + (long long)(v0 ? y : 0) * L.dpitch);
+                        const uint32_t* q1 = reinterpret_cast<const uint32_t*>(dI + (long long)(v1 ? y + 1 : 0) * L.dpitch);
 #pragma unroll
                         for (int k = 0; k < 5; ++k) {
                             const int xx = x + k;
                             const bool okx = xx >= 0 && xx < L.w;
-                            d0[k] = (okx && y >= 0 && y < L.h)
-                                        ? reinterpret_cast<const uint32_t*>(dI + (long long)y * L.dpitch)[xx] : 0u;
-                            d1[k] = (okx && y + 1 >= 0 && y + 1 < L.h)
-                                        ? reinterpret_cast<const uint32_t*>(dI + (long long)(y + 1) * L.dpitch)[xx] : 0u;
+                            d0[k] = (okx && v0) ? q0[xx] : 0u;
+                            d1[k] = (okx && v1) ? q1[xx] : 0u;
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (itx[p] + k < win_w) {
-                            const int ival = bilin_u8(r0, r1, k, W);
-                            const int x00 = (int)(short)(d0[k] & 0xffff),     y00 = (int)d0[k] >> 16;
-                            const int x01 = (int)(short)(d0[k + 1] & 0xffff), y01 = (int)d0[k + 1] >> 16;
-                            const int x10 = (int)(short)(d1[k] & 0xffff),     y10 = (int)d1[k] >> 16;
-                            const int x11 = (int)(short)(d1[k + 1] & 0xffff), y11 = (int)d1[k + 1] >> 16;
-                            const int ixval = (x00 * W.w00 + x01 * W.w01 + x10 * W.w10 + x11 * W.w11 + (1 << (W_BITS - 1))) >> W_BITS;
-                            const int iyval = (y00 * W.w00 + y01 * W.w01 + y10 * W.w10 + y11 * W.w11 + (1 << (W_BITS - 1))) >> W_BITS;
+                            const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
+                            const int ival  = bilin_u8(r, sel, W);
+                            const int ixval = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
+                            const int iyval = bilin_s16<0x07060302u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
                             Iv[p][k] = ival; Ix[p][k] = ixval; Iy[p][k] = iyval;
-                            s11 += (float)(ixval * ixval);
-                            s12 += (float)(ixval * iyval);
-                            s22 += (float)(iyval * iyval);
+                            s11 += (float)__mul24(ixval, ixval);
+                            s12 += (float)__mul24(ixval, iyval);
+                            s22 += (float)__mul24(iyval, iyval);
                         }
                     }
                 }
             }
-            A11 = wave_sum(s11) * FLT_SCALE;
-            A12 = wave_sum(s12) * FLT_SCALE;
-            A22 = wave_sum(s22) * FLT_SCALE;
+            float unused;
+            wave_sum2(s11, s12, A11, A12);
+            wave_sum2(s22, s22, A22, unused);
+            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
 
         float D = A11 * A22 - A12 * A12;
@@ -233,8 +329,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
         D = 1.f / D;
         cx -= half_x; cy -= half_y;
 
-        // ---- Gauss-Newton iterations ----------------------------------------------------------
-        const uint8_t* __restrict__ J = L.img + (long long)ns * L.step;
+        // ---- Gauss-Newton iterations (out of LDS) -----------------------------------------------
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cx));
@@ -244,26 +339,30 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
                 break;
             }
             it_count = j + 1;
+            if (!region_covers(R, inx, iny, rpr, win_h, rwd, rh))
+                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, a.cw_shift, lane);
             const Weights W = make_weights(cx - (float)inx, cy - (float)iny);
-            const bool inside = inx >= 0 && iny >= 0 && inx + win_w < L.w && iny + win_h < L.h;
+            const int o = inx & 3;
+            const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
+            const int base = (iny - R.y0) * lpd + (((inx & ~3) - R.x0) >> 2);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 if (ivalid[p]) {
-                    uint64_t r0, r1;
-                    if (inside) load_rows_fast(J, L.pitch, inx + itx[p], iny + ity[p], r0, r1);
-                    else        load_rows_slow(J, L.pitch, L.w, L.h, inx + itx[p], iny + ity[p], r0, r1);
+                    const Rows r = lds_rows(lds, lpd, base, loff[p]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         // masked taps carry Ix = Iy = 0: their terms are +0.0f, an exact no-op
-                        const int diff = bilin_u8(r0, r1, k, W) - Iv[p][k];
-                        s1 += (float)(diff * Ix[p][k]);
-                        s2 += (float)(diff * Iy[p][k]);
+                        const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
+                        const int diff = bilin_u8(r, sel, W) - Iv[p][k];
+                        s1 += (float)__mul24(diff, Ix[p][k]);
+                        s2 += (float)__mul24(diff, Iy[p][k]);
                     }
                 }
             }
-            const float b1 = wave_sum(s1) * FLT_SCALE;
-            const float b2 = wave_sum(s2) * FLT_SCALE;
+            float b1, b2;
+            wave_sum2(s1, s2, b1, b2);
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
 
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
@@ -290,25 +389,29 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
                 status = 0;
                 continue;
             }
+            if (!region_covers(R, inx, iny, rpr, win_h, rwd, rh))
+                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, a.cw_shift, lane);
             const Weights W = make_weights(fx - (float)inx, fy - (float)iny);
-            const bool inside = inx >= 0 && iny >= 0 && inx + win_w < L.w && iny + win_h < L.h;
+            const int o = inx & 3;
+            const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
+            const int base = (iny - R.y0) * lpd + (((inx & ~3) - R.x0) >> 2);
             float se = 0.f;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 if (ivalid[p]) {
-                    uint64_t r0, r1;
-                    if (inside) load_rows_fast(J, L.pitch, inx + itx[p], iny + ity[p], r0, r1);
-                    else        load_rows_slow(J, L.pitch, L.w, L.h, inx + itx[p], iny + ity[p], r0, r1);
+                    const Rows r = lds_rows(lds, lpd, base, loff[p]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (itx[p] + k < win_w) {
-                            const int diff = bilin_u8(r0, r1, k, W) - Iv[p][k];
+                            const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
+                            const int diff = bilin_u8(r, sel, W) - Iv[p][k];
                             se += fabsf((float)diff);
                         }
                     }
                 }
             }
-            const float errval = wave_sum(se);
+            float errval, unused;
+            wave_sum2(se, se, errval, unused);
             err = errval * 1.f / (float)(32 * win_w * win_h);
         }
     }
@@ -328,11 +431,12 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
     if (n_pairs <= 0 || a.n_pts <= 0) return hipSuccess;
     const int npass = (a.n_items + 63) / 64;
     dim3 grid(a.n_pts, n_pairs), block(64);
+    const size_t shmem = (size_t)a.rh * a.lpd * sizeof(uint32_t);
     switch (npass) {
-    case 1: hipLaunchKernelGGL((lk_track_kernel<1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((lk_track_kernel<2>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((lk_track_kernel<3>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((lk_track_kernel<4>), grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((lk_track_kernel<1>), grid, block, shmem, s, a); break;
+    case 2: hipLaunchKernelGGL((lk_track_kernel<2>), grid, block, shmem, s, a); break;
+    case 3: hipLaunchKernelGGL((lk_track_kernel<3>), grid, block, shmem, s, a); break;
+    case 4: hipLaunchKernelGGL((lk_track_kernel<4>), grid, block, shmem, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -180,14 +180,16 @@ static float wsum_get(wsum* s, int which)
 {
     if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
     {
-        float a[64], b[64];
+        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2): fold the upper half-wave
+         * onto the lower, xor butterfly 1,2,4,8 inside each row of 16 lanes, then R1 + R0 */
+        float a[32], b[32];
         int off, l;
-        memcpy(a, s->lane[which], sizeof(a));
-        for (off = 1; off < 64; off <<= 1) {          /* xor butterfly, stages 1,2,4,8,16,32 */
-            for (l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ off];
+        for (l = 0; l < 32; ++l) a[l] = s->lane[which][l] + s->lane[which][l + 32];
+        for (off = 1; off < 16; off <<= 1) {
+            for (l = 0; l < 32; ++l) b[l] = a[l] + a[l ^ off];
             memcpy(a, b, sizeof(a));
         }
-        return a[0];
+        return a[16] + a[0];
     }
 }
 

@@ -44,7 +44,7 @@ extern "C" {
 
 /* float summation order of the window sums (A11,A12,A22,b1,b2,err) */
 #define DR3O_ORDER_RASTER   0  /* OpenCV's scalar path: y outer, x inner, one f32 accumulator */
-#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order: 64 lanes x runs of 4 taps, xor butterfly */
+#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order: 64 lanes x runs of 4 taps; half-wave fold, xor butterfly per 16-lane row, R1+R0 */
 
 /* half-sample rounding / addressing modes (src/utils.cpp:382-419) */
 #define DR3O_HALF_TRUNC      0 /* row-aligned, (a+b+c+d)/4 truncating  (scalar :411, NEON :353-372) */
