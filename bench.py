@@ -202,7 +202,9 @@ def main(argv=None):
     d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
     d_st, d_err = ctx.alloc(B * N_PTS), ctx.alloc(B * N_PTS * 4)
     params = dr3.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
-    batch.build(0, 1, True)          # the frame carried over from the previous batch of the stream
+    # slot 0 stands for the frame carried over from the previous batch of the stream.  Build it with a
+    # full-size launch so that every launch rocprofv3 averages for this kernel has the same shape.
+    batch.build(0, B + 1, True)
 
     def step():
         batch.build(1, B, True)                                  # pyramid + gradient pass, B new frames

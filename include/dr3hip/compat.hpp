@@ -1,0 +1,193 @@
+// dr3hip/compat.hpp -- C++14 drop-in layer over the C ABI (include/dr3hip.h).
+//
+// It offers the four calls 3DR makes on its dense hot path with the argument lists OpenCV gives them,
+// so the reference's call sites change by namespace only:
+//     cv::calcOpticalFlowPyrLK   src/initialization.cpp:608-613   -> dr3hip::calcOpticalFlowPyrLK
+//     cv::warpPerspective        src/stitch.cpp:73-74, src/panorama.cpp:192 -> dr3hip::warpPerspective
+//     cv::remap                  src/utils.cpp:191                -> dr3hip::remap
+//     utils::create_img_pyramid  src/utils.cpp:421-430 (src/frame.cpp:18) -> dr3hip::create_img_pyramid
+// Images travel as MatView {data, rows, cols, step, type}: a plain view that a cv::Mat converts to
+// with MatView::of(mat) where OpenCV exists (define DR3HIP_WITH_OPENCV before including), so
+// include/features.hpp, include/stitch.hpp and include/panorama.hpp of the reference stay untouched.
+// Error behaviour mirrors OpenCV's: bad arguments / device errors throw (dr3hip::Error instead of
+// cv::Exception); per-point tracking failure is reported through status[i] == 0 only.
+#ifndef DR3HIP_COMPAT_HPP
+#define DR3HIP_COMPAT_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../dr3hip.h"
+
+#ifdef DR3HIP_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace dr3hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// cv-shaped value types (layout-compatible with cv::Point2f / cv::Size / cv::TermCriteria)
+struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
+struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };
+struct TermCriteria {
+    enum { COUNT = 1, MAX_ITER = 1, EPS = 2 };
+    int type; int maxCount; double epsilon;
+    TermCriteria() : type(COUNT + EPS), maxCount(30), epsilon(0.01) {}
+    TermCriteria(int t, int n, double e) : type(t), maxCount(n), epsilon(e) {}
+};
+enum { OPTFLOW_USE_INITIAL_FLOW = 4, OPTFLOW_LK_GET_MIN_EIGENVALS = 8 };
+enum { INTER_LINEAR = 1, WARP_INVERSE_MAP = 16 };
+
+// non-owning image view; type is one of DR3HIP_8UC1 / 8UC3 / 8UC4 / 32FC1 / 32FC4
+struct MatView {
+    void* data; int rows, cols; std::size_t step; int type;
+    MatView() : data(nullptr), rows(0), cols(0), step(0), type(DR3HIP_8UC1) {}
+    MatView(void* d, int r, int c, std::size_t s, int t) : data(d), rows(r), cols(c), step(s), type(t) {}
+    bool empty() const { return data == nullptr || rows <= 0 || cols <= 0; }
+    static int elem_size(int t) {
+        switch (t) { case DR3HIP_8UC1: return 1; case DR3HIP_8UC3: return 3; case DR3HIP_8UC4: return 4;
+                     case DR3HIP_32FC1: return 4; case DR3HIP_32FC4: return 16; default: return 0; }
+    }
+#ifdef DR3HIP_WITH_OPENCV
+    static MatView of(const cv::Mat& m) {
+        int t;
+        switch (m.type()) {
+        case CV_8UC1: t = DR3HIP_8UC1; break;   case CV_8UC3: t = DR3HIP_8UC3; break;
+        case CV_8UC4: t = DR3HIP_8UC4; break;   case CV_32FC1: t = DR3HIP_32FC1; break;
+        case CV_32FC4: t = DR3HIP_32FC4; break;
+        default: throw Error(DR3HIP_EINVAL, "dr3hip::MatView::of: unsupported cv::Mat type");
+        }
+        return MatView(m.data, m.rows, m.cols, m.step, t);
+    }
+#endif
+};
+
+// owning image for outputs the reference receives as freshly created cv::Mat
+struct Image {
+    std::vector<unsigned char> buf; int rows, cols, type; std::size_t step;
+    Image() : rows(0), cols(0), type(DR3HIP_8UC1), step(0) {}
+    void create(int r, int c, int t) {
+        rows = r; cols = c; type = t; step = (std::size_t)c * MatView::elem_size(t);
+        buf.assign(step * (std::size_t)r, 0);
+    }
+    MatView view() { return MatView(buf.data(), rows, cols, step, type); }
+    unsigned char* ptr(int r) { return buf.data() + step * (std::size_t)r; }
+};
+
+// One context per thread per device, created on first use (the reference is single-threaded;
+// a dr3hip_ctx is not thread-safe, distinct ones are).
+class Context {
+public:
+    static Context& instance(int device = 0) {
+        static thread_local Context c(device);
+        if (c.device_ != device) throw Error(DR3HIP_EINVAL, "dr3hip::Context: one device per thread");
+        return c;
+    }
+    dr3hip_ctx* get() const { return ctx_; }
+    int check(int rc, const char* where) const {
+        if (rc < 0) throw Error(rc, std::string(where) + ": " + dr3hip_last_error(ctx_));
+        return rc;
+    }
+    ~Context() { dr3hip_destroy(ctx_); }
+private:
+    explicit Context(int device) : ctx_(nullptr), device_(device) {
+        const int rc = dr3hip_init(device, &ctx_);
+        if (rc != DR3HIP_OK) throw Error(rc, std::string("dr3hip_init: ") + dr3hip_last_error(nullptr));
+    }
+    Context(const Context&); Context& operator=(const Context&);
+    dr3hip_ctx* ctx_; int device_;
+};
+
+// cv::calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, status, err, winSize, maxLevel,
+//                          criteria, flags, minEigThreshold)
+inline int calcOpticalFlowPyrLK(const MatView& prevImg, const MatView& nextImg,
+                                const std::vector<Point2f>& prevPts, std::vector<Point2f>& nextPts,
+                                std::vector<unsigned char>& status, std::vector<float>& err,
+                                Size winSize = Size(21, 21), int maxLevel = 3,
+                                TermCriteria criteria = TermCriteria(), int flags = 0,
+                                double minEigThreshold = 1e-4, int device = 0)
+{
+    if (prevImg.empty() || nextImg.empty() || prevImg.type != DR3HIP_8UC1 || nextImg.type != DR3HIP_8UC1 ||
+        prevImg.rows != nextImg.rows || prevImg.cols != nextImg.cols)
+        throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: 8-bit single-channel images of equal size expected");
+    const std::size_t n = prevPts.size();
+    if (flags & OPTFLOW_USE_INITIAL_FLOW) {
+        if (nextPts.size() != n) throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: nextPts.size() != prevPts.size() with USE_INITIAL_FLOW");
+    } else {
+        nextPts.resize(n);
+    }
+    status.assign(n, 1);
+    err.assign(n, 0.f);
+    dr3hip_lk_params p;
+    p.win_w = winSize.width; p.win_h = winSize.height; p.max_level = maxLevel;
+    p.crit_type = criteria.type; p.max_iters = criteria.maxCount; p.eps = criteria.epsilon;
+    p.flags = flags; p.min_eig_threshold = minEigThreshold;
+    Context& c = Context::instance(device);
+    static_assert(sizeof(Point2f) == 2 * sizeof(float), "Point2f must be two packed floats");
+    return c.check(dr3hip_lk_track(c.get(), static_cast<const uint8_t*>(prevImg.data), static_cast<const uint8_t*>(nextImg.data),
+                                   prevImg.cols, prevImg.rows, (int)prevImg.step, (int)nextImg.step,
+                                   n ? &prevPts[0].x : nullptr, n ? &nextPts[0].x : nullptr, (int)n,
+                                   n ? status.data() : nullptr, n ? err.data() : nullptr, &p),
+                   "calcOpticalFlowPyrLK");
+}
+
+// cv::warpPerspective(src, dst, M, dsize, flags = INTER_LINEAR, BORDER_CONSTANT, 0); M: 3x3 f32 row-major
+inline void warpPerspective(const MatView& src, Image& dst, const float M[9], Size dsize, int flags = INTER_LINEAR, int device = 0)
+{
+    if (src.empty()) throw Error(DR3HIP_EINVAL, "warpPerspective: empty source");
+    if ((flags & 7) != INTER_LINEAR) throw Error(DR3HIP_EINVAL, "warpPerspective: only INTER_LINEAR is implemented (the reference uses no other)");
+    dst.create(dsize.height > 0 ? dsize.height : src.rows, dsize.width > 0 ? dsize.width : src.cols, src.type);
+    Context& c = Context::instance(device);
+    c.check(dr3hip_warp_perspective(c.get(), src.data, src.cols, src.rows, (int)src.step, src.type,
+                                    dst.buf.data(), dst.cols, dst.rows, (int)dst.step, M,
+                                    (flags & WARP_INVERSE_MAP) ? DR3HIP_WARP_INVERSE_MAP : 0), "warpPerspective");
+}
+
+// cv::remap(src, dst, map1 (CV_32FC1 x), map2 (CV_32FC1 y), INTER_LINEAR)
+inline void remap(const MatView& src, Image& dst, const MatView& map1, const MatView& map2, int interpolation = INTER_LINEAR, int device = 0)
+{
+    if (src.empty() || map1.empty() || map2.empty() || map1.type != DR3HIP_32FC1 || map2.type != DR3HIP_32FC1 ||
+        map1.rows != map2.rows || map1.cols != map2.cols || map1.step != map2.step)
+        throw Error(DR3HIP_EINVAL, "remap: CV_32FC1 maps of equal size expected");
+    if (interpolation != INTER_LINEAR) throw Error(DR3HIP_EINVAL, "remap: only INTER_LINEAR is implemented");
+    dst.create(map1.rows, map1.cols, src.type);
+    Context& c = Context::instance(device);
+    c.check(dr3hip_remap_bilinear(c.get(), src.data, src.cols, src.rows, (int)src.step, src.type,
+                                  dst.buf.data(), dst.cols, dst.rows, (int)dst.step,
+                                  static_cast<const float*>(map1.data), static_cast<const float*>(map2.data), (int)map1.step), "remap");
+}
+
+// utils::create_img_pyramid(img_lvl_0, n_levels, pyr).  Level 0 is a copy of the input (the
+// reference stores the cv::Mat header, i.e. shares the pixels); levels 1.. are floor-halved.
+// mode DR3HIP_HALF_REF_X86 reproduces what the reference executes on x86-64 byte for byte.
+inline void create_img_pyramid(const MatView& img_lvl_0, int n_levels, std::vector<Image>& pyr,
+                               int mode = DR3HIP_HALF_REF_X86, int device = 0)
+{
+    if (img_lvl_0.empty() || img_lvl_0.type != DR3HIP_8UC1 || n_levels < 1)
+        throw Error(DR3HIP_EINVAL, "create_img_pyramid: 8-bit gray image and n_levels >= 1 expected");
+    pyr.resize((std::size_t)n_levels);
+    pyr[0].create(img_lvl_0.rows, img_lvl_0.cols, DR3HIP_8UC1);
+    for (int r = 0; r < img_lvl_0.rows; ++r)
+        std::memcpy(pyr[0].ptr(r), static_cast<const unsigned char*>(img_lvl_0.data) + img_lvl_0.step * (std::size_t)r, (std::size_t)img_lvl_0.cols);
+    std::vector<uint8_t*> ptrs((std::size_t)n_levels, nullptr);
+    std::vector<int> strides((std::size_t)n_levels, 0);
+    for (int l = 1; l < n_levels; ++l) {
+        pyr[l].create(pyr[l - 1].rows / 2, pyr[l - 1].cols / 2, DR3HIP_8UC1);
+        ptrs[l] = pyr[l].buf.data(); strides[l] = (int)pyr[l].step;
+        if (pyr[l].rows == 0 || pyr[l].cols == 0) throw Error(DR3HIP_EINVAL, "create_img_pyramid: too many levels for this image");
+    }
+    Context& c = Context::instance(device);
+    c.check(dr3hip_halfsample_pyramid(c.get(), static_cast<const uint8_t*>(img_lvl_0.data), img_lvl_0.cols, img_lvl_0.rows,
+                                      (int)img_lvl_0.step, n_levels, mode, ptrs.data(), strides.data()), "create_img_pyramid");
+}
+
+}  // namespace dr3hip
+#endif  // DR3HIP_COMPAT_HPP
