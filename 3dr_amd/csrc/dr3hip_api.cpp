@@ -384,7 +384,7 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
     for (int l = 0; l <= L; ++l) {
         const bool down = l < L, deriv = with_deriv != 0;
         if (!down && !deriv) continue;
-        for (int s0 = 0; s0 < count; s0 += 32768) {            // grid.z limit
+        for (int s0 = 0; s0 < count; s0 += 32768) {            // keeps tiles * slots far below 2^31 blocks
             PyrArgs a;
             a.src = b->lv[l];
             a.dst = down ? b->lv[l + 1] : b->lv[l];

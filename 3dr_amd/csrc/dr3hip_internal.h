@@ -25,7 +25,9 @@ struct LevelDev {
 struct PyrArgs {
     LevelDev src;          // level l
     LevelDev dst;          // level l + 1 (unused when !DOWN)
-    int first;             // first slot; blockIdx.z is added
+    int first;             // first slot of the launch
+    int tiles_x, tiles_y;  // filled by the launcher
+    int n_swz;             // slots (multiple of 8) covered by the XCD-aware block map
 };
 
 struct LKArgs {

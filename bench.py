@@ -178,14 +178,18 @@ def main(argv=None):
     # torch first: its bundled libamdhip64 and ours share one SONAME, so whichever is loaded first
     # serves both; loading torch's first keeps a single HIP runtime in the process.
     import torch
-    dist = Dist(args.gpus, backend="nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # DR3_BENCH_BACKEND=gloo rehearses the N>1 protocol on a box with fewer GPUs than ranks (the ranks then
+    # share devices; RCCL refuses two ranks on one GPU).  The driver's runs use the default, nccl == RCCL.
+    backend = os.environ.get("DR3_BENCH_BACKEND", "nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+    dist = Dist(args.gpus, backend=backend)
     dr3 = importlib.import_module("3dr_amd")
     synth = importlib.import_module("3dr_amd.synth")
 
     fx, fy, cx, cy, Wf, Hf = dist.bcast_intrinsics(INTRINSICS)
     W, H = int(Wf), int(Hf)
     B = args.batch
-    ctx = dr3.Context(dist.local_rank)
+    n_dev = dr3.lib().dr3hip_device_count()
+    ctx = dr3.Context(dist.local_rank % max(n_dev, 1))
 
     def sync():
         ctx.sync()
