@@ -1,12 +1,8 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-run() { # name counters...
-  n=$1; shift
+run() { n=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$n -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-warp > $R/gpurun_out/pmc_$n.log 2>&1 || echo "pmc $n failed"
 }
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS
-run b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LEVEL_WAVES
-run c GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_MUL_I32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32
-run d TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
-run e TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
+run b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU
