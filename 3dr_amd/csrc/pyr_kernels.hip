@@ -23,6 +23,10 @@ constexpr int LP = 144;            // LDS row pitch in bytes (multiple of 8)
 constexpr int LR = TH + 4;         // LDS rows: y0-2 .. y0+TH+1
 constexpr int NT = 256;
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -62,11 +66,7 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
         const int y = reflect101(y0 - 2 + r, h);
         const int x = x0 - 4 + 4 * c;
         uint32_t v = 0;
-#if defined(DR3_DBG_PYR_NOLOAD)
-        v = (uint32_t)(i * 2654435761u) ^ (uint32_t)(y + x);
-#else
         if (x >= 0 && x < pitch) v = *reinterpret_cast<const uint32_t*>(src + (long long)y * pitch + x);
-#endif
         *reinterpret_cast<uint32_t*>(tile + r * LP + 4 * c) = v;
     }
     __syncthreads();
@@ -96,37 +96,41 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
             const int r = i / (TW / 4), c4 = i - r * (TW / 4);
             const int x = x0 + 4 * c4, y = y0 + r;
             if (x < w && y < h) {
-                // image columns x-1 .. x+4  ->  LDS bytes 4*c4+3 .. 4*c4+8 of rows r+1 .. r+3
-                int t0[6], t1[6];
+                // image columns x-1 .. x+4  ->  LDS bytes 4*c4+3 .. 4*c4+8 of rows r+1 .. r+3.
+                // Packed 16-bit lanes: per row the six columns become three u16 pairs A = (-1,0),
+                // B = (1,2), C = (3,4) (one v_perm_b32 each); the vertical [3 10 3] / [-1 0 1] and the
+                // horizontal differences then run two columns per v_pk_* instruction.
                 const uint32_t* p0 = reinterpret_cast<const uint32_t*>(tile + (r + 1) * LP) + c4;
                 const uint32_t* p1 = reinterpret_cast<const uint32_t*>(tile + (r + 2) * LP) + c4;
                 const uint32_t* p2 = reinterpret_cast<const uint32_t*>(tile + (r + 3) * LP) + c4;
                 const uint32_t u0 = p0[0], u1 = p0[1], u2 = p0[2];
                 const uint32_t m0 = p1[0], m1 = p1[1], m2 = p1[2];
                 const uint32_t d0 = p2[0], d1 = p2[1], d2 = p2[2];
-                auto col = [](uint32_t q0, uint32_t q1, uint32_t q2, int k) -> int {
-                    return k == 0 ? (int)(q0 >> 24) : k == 5 ? (int)(q2 & 0xff) : (int)((q1 >> (8 * (k - 1))) & 0xff);
-                };
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int up = col(u0, u1, u2, k), mid = col(m0, m1, m2, k), dn = col(d0, d1, d2, k);
-                    t0[k] = (up + dn) * 3 + mid * 10;
-                    t1[k] = dn - up;
-                }
+                constexpr uint32_t SEL_EDGE = 0x0c040c03u;   // (S1.byte3, S0.byte0) -> two u16
+                constexpr uint32_t SEL_MID  = 0x0c020c01u;   // (S1.byte1, S1.byte2) -> two u16
+                const u16x2 uA = as_u16x2(__builtin_amdgcn_perm(u1, u0, SEL_EDGE)), uB = as_u16x2(__builtin_amdgcn_perm(u1, u1, SEL_MID)),
+                            uC = as_u16x2(__builtin_amdgcn_perm(u2, u1, SEL_EDGE));
+                const u16x2 mA = as_u16x2(__builtin_amdgcn_perm(m1, m0, SEL_EDGE)), mB = as_u16x2(__builtin_amdgcn_perm(m1, m1, SEL_MID)),
+                            mC = as_u16x2(__builtin_amdgcn_perm(m2, m1, SEL_EDGE));
+                const u16x2 dA = as_u16x2(__builtin_amdgcn_perm(d1, d0, SEL_EDGE)), dB = as_u16x2(__builtin_amdgcn_perm(d1, d1, SEL_MID)),
+                            dC = as_u16x2(__builtin_amdgcn_perm(d2, d1, SEL_EDGE));
+                const u16x2 three = {3, 3}, ten = {10, 10};
+                // t0 = 3 (up + dn) + 10 mid ; t1 = dn - up   (mod 2^16 == exact: |values| <= 4080)
+                const u16x2 t0A = (uA + dA) * three + mA * ten, t0B = (uB + dB) * three + mB * ten, t0C = (uC + dC) * three + mC * ten;
+                const u16x2 t1A = dA - uA, t1B = dB - uB, t1C = dC - uC;
+                const u16x2 ix01 = t0B - t0A, ix23 = t0C - t0B;                 // t0[k+1] - t0[k-1]
+                const u16x2 t1M = as_u16x2(__builtin_amdgcn_alignbit(as_u32(t1B), as_u32(t1A), 16));   // (t1[0], t1[1])
+                const u16x2 t1N = as_u16x2(__builtin_amdgcn_alignbit(as_u32(t1C), as_u32(t1B), 16));   // (t1[2], t1[3])
+                const u16x2 iy01 = (t1A + t1B) * three + t1M * ten, iy23 = (t1B + t1C) * three + t1N * ten;
                 uint32_t o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ix = t0[k + 2] - t0[k];
-                    const int iy = (t1[k] + t1[k + 2]) * 3 + t1[k + 1] * 10;
-                    o[k] = ((uint32_t)ix & 0xffffu) | ((uint32_t)iy << 16);
-                }
+                o[0] = __builtin_amdgcn_perm(as_u32(iy01), as_u32(ix01), 0x05040100u);   // (Ix0, Iy0)
+                o[1] = __builtin_amdgcn_perm(as_u32(iy01), as_u32(ix01), 0x07060302u);   // (Ix1, Iy1)
+                o[2] = __builtin_amdgcn_perm(as_u32(iy23), as_u32(ix23), 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(as_u32(iy23), as_u32(ix23), 0x07060302u);
                 // zero the lanes' pixels beyond w so the pitch slack stays deterministic
 #pragma unroll
                 for (int k = 1; k < 4; ++k) if (x + k >= w) o[k] = 0;
                 uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-#if defined(DR3_DBG_PYR_NOSTORE)
-                if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345677u)
-#endif
                 *reinterpret_cast<uint4*>(der + (long long)y * a.src.dpitch + 4 * x) = v;
             }
         }
@@ -139,29 +143,30 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
         const int yi = tid / (TW / 8), g = tid - yi * (TW / 8);
         const int X = x0 / 2 + 4 * g, Y = y0 / 2 + yi;
         if (X < dw && Y < dh) {
-            int acc[4] = {0, 0, 0, 0};
+            // v_dot4_u32_u8: the horizontal taps (1,4,6,4) of one output are one dot4 on 4 consecutive bytes,
+            // the fifth tap a second dot4 with weights (1,0,0,0) on the next 4; the vertical weight of row j
+            // is folded into both byte-weight vectors, so an output is a chain of 10 dot4 accumulations.
+            uint32_t acc[4] = {128u, 128u, 128u, 128u};                       // rounding term of (v + 128) >> 8
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 // image columns 2X-2 .. 2X+8  ->  LDS bytes 8g+2 .. 8g+12 of row 2*yi + j
-                const uint64_t* q = reinterpret_cast<const uint64_t*>(tile + (2 * yi + j) * LP + 8 * g);
-                const uint64_t lo = q[0], hi = q[1];
-                int b[11];
-#pragma unroll
-                for (int m = 0; m < 11; ++m) {
-                    const int off = m + 2;
-                    b[m] = off < 8 ? (int)((lo >> (8 * off)) & 0xff) : (int)((hi >> (8 * (off - 8))) & 0xff);
-                }
-                const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int hs = b[2 * k + 2] * 6 + (b[2 * k + 1] + b[2 * k + 3]) * 4 + b[2 * k] + b[2 * k + 4];
-                    acc[k] += wj * hs;
-                }
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(tile + (2 * yi + j) * LP + 8 * g);
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+                const uint32_t wj = (j == 0 || j == 4) ? 1u : (j == 2 ? 6u : 4u);
+                const uint32_t Wv = wj * 0x04060401u;                            // (1,4,6,4) * wj, each <= 36
+                const uint32_t Ev = wj;                                          // (1,0,0,0) * wj
+                const uint32_t a02 = __builtin_amdgcn_alignbyte(w1, w0, 2);     // bytes 2..5
+                const uint32_t a06 = __builtin_amdgcn_alignbyte(w2, w1, 2);     // bytes 6..9
+                const uint32_t a10 = __builtin_amdgcn_alignbyte(w3, w2, 2);     // bytes 10..13
+                acc[0] = __builtin_amdgcn_udot4(a02, Wv, __builtin_amdgcn_udot4(a06, Ev, acc[0], false), false);
+                acc[1] = __builtin_amdgcn_udot4(w1,  Wv, __builtin_amdgcn_udot4(w2,  Ev, acc[1], false), false);
+                acc[2] = __builtin_amdgcn_udot4(a06, Wv, __builtin_amdgcn_udot4(a10, Ev, acc[2], false), false);
+                acc[3] = __builtin_amdgcn_udot4(w2,  Wv, __builtin_amdgcn_udot4(w3,  Ev, acc[3], false), false);
             }
             uint32_t o = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t v = (X + k < dw) ? (uint32_t)((acc[k] + 128) >> 8) : 0u;
+                const uint32_t v = (X + k < dw) ? (acc[k] >> 8) : 0u;
                 o |= v << (8 * k);
             }
             *reinterpret_cast<uint32_t*>(dst + (long long)Y * a.dst.pitch + X) = o;
