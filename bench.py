@@ -118,6 +118,27 @@ def aggregate_rate(dist, units_this_rank, elapsed_max):
 # ----------------------------------------------------------------------------------------------
 # algorithmic bytes
 # ----------------------------------------------------------------------------------------------
+def pmc_traffic(kernel_substr, batch):
+    """HBM bytes per launch of one kernel from the newest committed PMC summary (profiles/*/pmc_traffic.json,
+    made by tools/profile_bench.sh + tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same script; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).
+    PMC counters cannot be collected from inside the process being timed, so the figure is the recorded one
+    for the same launch shape (default --batch); any other shape reports None."""
+    if batch != 256:
+        return None, None
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        for d in sorted(os.listdir(root), reverse=True):
+            f = os.path.join(root, d, "pmc_traffic.json")
+            if os.path.exists(f):
+                for name, t in json.load(open(f))["kernels"].items():
+                    if kernel_substr in name and "hbm_bytes" in t:
+                        return t["hbm_bytes"], "profiles/%s/pmc_traffic.json" % d
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def level_sizes(w, h, levels):
     out = []
     for _ in range(levels):
@@ -256,6 +277,7 @@ def main(argv=None):
         lk_ms = ms_lk / max(n_lk, 1)
         ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
         ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
+        traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B)
         out = {
             "metric": "tracked_keypoints_per_sec",
             "value": kps,
@@ -279,7 +301,9 @@ def main(argv=None):
             "verified_vs_oracle": verified,
             "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)",
                          "bound": "hbm", "achieved": ach_l0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": traffic_l0,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_l0, "avg_launch_ms": l0_ms, "launches": n_l0},
             "roofline_pyr_grad_pass": {"kernel": "all %d level launches of one pyramid+gradient pass" % levels,
                                        "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
