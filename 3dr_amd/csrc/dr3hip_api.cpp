@@ -3,6 +3,7 @@
 // Compiled by hipcc as host code (-ffp-contract=off: the homography inversion below must round
 // like cv::invert does on the reference's x86-64 build).
 #include "dr3hip_internal.h"
+#include <cmath>
 
 #include <cstdarg>
 #include <cstdio>
@@ -578,6 +579,34 @@ static bool invert3x3(const double S[9], double T[9])
     return true;
 }
 
+// May the kernel use its guarded fast coordinate path (warp_kernels.hip, persp_tap_fast)?  W = M6 x + M7 y + M8
+// is linear, so its extremes over the destination are at the corners.  Conditions: source <= 8191 x 8191 and
+// all source coordinates within +-8000 px (13 extra fraction bits fit int32), every M finite, W of one sign with |W| >= 1e-6 max|W| and within
+// [1e-100, 1e100], and numerator operands bounded by 2^32 |W|min: then the FMA/Newton evaluation differs
+// from the exact f64 sequence by < 2^-52 * 2^32 * 2^18 = 1/4 unit of the 2-unit tie guard.
+static bool warp_fast_coords_ok(const double M[9], int sw, int sh, int dw, int dh)
+{
+    if (sw > 8191 || sh > 8191 || dw <= 0 || dh <= 0) return false;
+    for (int i = 0; i < 9; ++i) if (!std::isfinite(M[i])) return false;
+    const double xs[2] = {0.0, (double)(dw - 1)}, ys[2] = {0.0, (double)(dh - 1)};
+    double wmin = INFINITY, wmax = 0.0; int pos = 0, neg = 0;
+    bool in_range = true;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        const double w = M[6] * xs[a] + M[7] * ys[b] + M[8];
+        (w > 0 ? pos : neg)++;
+        wmin = std::fmin(wmin, std::fabs(w)); wmax = std::fmax(wmax, std::fabs(w));
+        // the destination maps onto a convex quadrilateral (W of one sign): its corners bound every pixel
+        const double sx = (M[0] * xs[a] + M[1] * ys[b] + M[2]) / w, sy = (M[3] * xs[a] + M[4] * ys[b] + M[5]) / w;
+        if (!(std::fabs(sx) < 8000.0) || !(std::fabs(sy) < 8000.0)) in_range = false;
+    }
+    if (!in_range) return false;
+    if (pos != 4 && neg != 4) return false;
+    if (!(wmin >= 1e-100) || !(wmax <= 1e100) || wmin < 1e-6 * wmax) return false;
+    const double bx = std::fabs(M[0]) * dw + std::fabs(M[1]) * dh + std::fabs(M[2]);
+    const double by = std::fabs(M[3]) * dw + std::fabs(M[4]) * dh + std::fabs(M[5]);
+    return bx < 4294967296.0 * wmin && by < 4294967296.0 * wmin;
+}
+
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags)
 {
@@ -590,6 +619,10 @@ static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride
     // WarpPerspectiveInvoker block geometry (only the x0 + x1 split is observable)
     const int bh0 = dh < 16 ? dh : 16;
     j.bw0 = (1024 / bh0) < dw ? (1024 / bh0) : dw;
+    j.bw0_shift = -1;
+    if (j.bw0 >= dw) j.bw0_shift = 31;                                    // x0 == 0 for every x
+    else if (j.bw0 >= 64 && (j.bw0 & (j.bw0 - 1)) == 0) j.bw0_shift = __builtin_ctz((unsigned)j.bw0);
+    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? 1 : 0;
 }
 
 int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs, int type, int flags)
@@ -602,6 +635,7 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
     const int esz = type_elem_bytes(type);
     std::vector<WarpJobDev> hj(n_jobs);
     int max_dw = 0, max_dh = 0;
+    bool generic = false;
     for (int i = 0; i < n_jobs; ++i) {
         const dr3hip_warp_job& q = jobs[i];
         if (!q.src || !q.dst || q.sw < 1 || q.sh < 1 || q.dw < 1 || q.dh < 1 || q.sstride < q.sw * esz || q.dstride < q.dw * esz)
@@ -611,6 +645,7 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
         make_job(hj[i], q.src, q.sw, q.sh, q.sstride, q.dst, q.dw, q.dh, q.dstride, q.M, flags);
         if (q.dw > max_dw) max_dw = q.dw;
         if (q.dh > max_dh) max_dh = q.dh;
+        if (hj[i].bw0_shift < 0) generic = true;
     }
     int rc;
     if ((rc = stage_reserve(ctx, 5, sizeof(WarpJobDev) * (size_t)n_jobs))) return rc;
@@ -618,7 +653,7 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
     HIPCHK(ctx, hipMemcpyAsync(ctx->stage[5].p, hj.data(), sizeof(WarpJobDev) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_WARP, pe);
-    HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p, n_jobs, max_dw, max_dh, type, ctx->stream));
+    HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p, n_jobs, max_dw, max_dh, type, generic, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

@@ -58,6 +58,8 @@ struct WarpJobDev {
     uint8_t* dst;       int dw, dh, dstride;
     double M[9];        // inverse map (dst -> src), already inverted on the host
     int bw0;            // WarpPerspectiveInvoker block width (x0/x1 split)
+    int bw0_shift;      // log2(bw0) if bw0 is a power of two >= 64; 31 if one block spans the row; else -1 (generic kernel)
+    int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191)
 };
 
 struct RemapArgs {
@@ -75,7 +77,7 @@ struct HalfArgs {
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
-hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, hipStream_t s);
+hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 

@@ -4,57 +4,142 @@
 //                      src/panorama.cpp:192 (32FC4)            -- SURVEY Appendix A-4
 //   remap            : cv::remap at reference src/utils.cpp:191 -- Appendix A-5
 //   halfsample       : utils::reduce_to_half, reference src/utils.cpp:382-419 (SSE2 :324-349)
-// All three are HBM-bound gathers/streams: one lane owns 4 adjacent destination pixels (8-bit
-// 1/3-channel types, dword stores, 768 B contiguous per wave for 8UC3) or one pixel (4-byte and
-// 16-byte pixel types), source taps come through the vector L1/L2.  Coordinates follow OpenCV
-// bit for bit: f64 homography evaluation with the WarpPerspectiveInvoker's x0+x1 block split,
-// round-half-even to 1/32 px, 15-bit integer weights for 8-bit data, f32 table weights summed left
-// to right without FMA contraction for f32 data.
+// All three are gathers/streams: one lane owns 4 adjacent destination pixels (8-bit 1/3-channel
+// types, dword stores; a wave is a 64 x 4 pixel tile, a block OpenCV's own 64 x 16 block) or one
+// pixel (4-byte and 16-byte pixel types), source taps come through the vector L1/L2.  Coordinates
+// follow OpenCV bit for bit: f64 homography evaluation with the WarpPerspectiveInvoker's x0+x1
+// block split, round-half-even to 1/32 px (a guarded fast evaluation hands every near-tie to the
+// exact sequence), 15-bit integer weights for 8-bit data (evaluated as perm + dot4), f32 table
+// weights summed left to right without FMA contraction for f32 data.
 #include "dr3hip_internal.h"
 
 namespace dr3 {
 namespace {
 
+// Pointers read out of job structs are generic to the compiler and would become flat_load/flat_store;
+// every image access goes through explicit global (address space 1) pointers instead.
+#define DR3_G __attribute__((address_space(1)))
+using gcu8 = const DR3_G uint8_t*;
+using gu8  = DR3_G uint8_t*;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ const DR3_G T* gcast(gcu8 p) { return reinterpret_cast<const DR3_G T*>(p); }
+template <class T> __device__ __forceinline__ DR3_G T* gcast(gu8 p) { return reinterpret_cast<DR3_G T*>(p); }
+
 struct Tap { int sx, sy, fx, fy; };
 
 __device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 
-// std::max((double)INT_MIN, std::min((double)INT_MAX, v)) with the std:: argument order
-__device__ __forceinline__ double clamp_int_range(double v)
+__device__ __forceinline__ Tap tap_from_fixed(int X, int Y)
 {
-    const double hi = 2147483647.0, lo = -2147483648.0;
-    const double m = (v < hi) ? v : hi;
-    return (lo < m) ? m : lo;
-}
-
-__device__ __forceinline__ Tap persp_tap(const double* __restrict__ M, int bw0, int bw0_shift, int x, int y)
-{
-    const int x0 = bw0_shift >= 0 ? ((x >> bw0_shift) << bw0_shift) : (x / bw0) * bw0;
-    const int x1 = x - x0;
-    const double X0 = M[0] * x0 + M[1] * y + M[2];
-    const double Y0 = M[3] * x0 + M[4] * y + M[5];
-    const double W0 = M[6] * x0 + M[7] * y + M[8];
-    double W = W0 + M[6] * x1;
-    W = (W != 0.0) ? 32.0 / W : 0.0;
-    const double fX = clamp_int_range((X0 + M[0] * x1) * W);
-    const double fY = clamp_int_range((Y0 + M[3] * x1) * W);
-    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
-    Tap t;
-    t.sx = sat_s16(X >> 5); t.sy = sat_s16(Y >> 5); t.fx = X & 31; t.fy = Y & 31;
+    Tap t; t.sx = sat_s16(X >> 5); t.sy = sat_s16(Y >> 5); t.fx = X & 31; t.fy = Y & 31;
     return t;
 }
 
-__device__ __forceinline__ void weights_8u(int fx, int fy, int w[4])
+// std::max((double)INT_MIN, std::min((double)INT_MAX, v)) with the std:: argument order: a NaN v
+// becomes INT_MAX, which is also what fmin (IEEE minNum, one v_min_f64) returns.
+__device__ __forceinline__ double clamp_int_range(double v)
 {
-    w[0] = (32 - fx) * (32 - fy) * 32; w[1] = fx * (32 - fy) * 32;
-    w[2] = (32 - fx) * fy * 32;        w[3] = fx * fy * 32;
-    if ((fx | fy) == 0) { w[0] = 32767; w[3] = 1; }   // OpenCV's saturated table entry + sum repair
+    return __builtin_fmax(-2147483648.0, __builtin_fmin(2147483647.0, v));
 }
+
+// WarpPerspectiveInvoker coordinates (SURVEY A-4): the block origin x0 contributes X0/Y0/W0, the
+// offset x1 inside the block is added per pixel; every product and sum is a separate f64 rounding.
+struct PerspBase { double X0, Y0, W0; };
+
+__device__ __forceinline__ PerspBase persp_base(const double* __restrict__ M, int x0, int y)
+{
+    PerspBase b;
+    b.X0 = M[0] * x0 + M[1] * y + M[2];
+    b.Y0 = M[3] * x0 + M[4] * y + M[5];
+    b.W0 = M[6] * x0 + M[7] * y + M[8];
+    return b;
+}
+__device__ __forceinline__ Tap persp_tap(const double* __restrict__ M, const PerspBase& b, double x1)
+{
+    double W = b.W0 + M[6] * x1;
+    W = (W != 0.0) ? 32.0 / W : 0.0;
+    const double fX = clamp_int_range((b.X0 + M[0] * x1) * W);
+    const double fY = clamp_int_range((b.Y0 + M[3] * x1) * W);
+    return tap_from_fixed(__double2int_rn(fX), __double2int_rn(fY));
+}
+__device__ __forceinline__ int block_origin(int x, int bw0, int bw0_shift)
+{
+    return bw0_shift >= 0 ? ((x >> bw0_shift) << bw0_shift) : (x / bw0) * bw0;
+}
+// Fast coordinates.  The exact path costs ~55 VALU-cycles-equivalents per pixel (f64 divide expansion,
+// clamps, conversions) and makes the 8-bit warp VALU-bound.  The fast path evaluates the same rational
+// function with FMAs and v_rcp_f64 + one Newton step (relative error < 2^-45), converts to fixed point
+// with 13 extra fraction bits and is only accepted when the value is at least 2 units (2^-13 of 1/32 px)
+// away from a rounding tie; otherwise -- ~5e-4 of the pixels -- the exact path recomputes the pixel, so the
+// result is bit-identical by construction.  Valid while |src coordinate| < 8192 px decides inside/outside
+// the same way.  The job flag `fast` is set by the host (make_job, warp_fast_coords_ok) only if, over the
+// whole destination, W keeps its sign and stays away from 0, the numerator operands are < 2^32 * |W| (which
+// bounds the fast path's deviation from the exact value by 1/4 unit) and every source coordinate lies
+// within +-8000 px, so the fixed-point value fits int32 and the conversion is always in range.
+struct PerspFast { double X0s, Y0s, M0s, M3s; };          // numerators pre-scaled by 32 * 2^13
+
+__device__ __forceinline__ bool persp_tap_fast(const double* __restrict__ M, const PerspBase& b, const PerspFast& f,
+                                               double x1, Tap& t)
+{
+    const double W = __builtin_fma(M[6], x1, b.W0);
+    double r = __builtin_amdgcn_rcp(W);                 // v_rcp_f64, ~2^-24 relative
+    r = __builtin_fma(__builtin_fma(-W, r, 1.0), r, r);
+    const int aX = (int)(__builtin_fma(f.M0s, x1, f.X0s) * r) + 4096;    // |.| < 2^31: host check
+    const int aY = (int)(__builtin_fma(f.M3s, x1, f.Y0s) * r) + 4096;
+    t.sx = aX >> 18; t.fx = (aX >> 13) & 31;
+    t.sy = aY >> 18; t.fy = (aY >> 13) & 31;
+    const bool near_tie = (((uint32_t)(aX + 2) & 8191u) < 4u) | (((uint32_t)(aY + 2) & 8191u) < 4u);
+    return !near_tie;
+}
+
+// NPX adjacent destination pixels x..x+NPX-1 of row y.  They share the block origin whenever the
+// block width is a multiple of NPX (always, except for destinations shorter than 16 rows).
+template <int NPX, bool GENERIC>
+__device__ __forceinline__ void persp_taps(const double* __restrict__ M, int bw0, int bw0_shift, bool fast, int x, int y, Tap t[NPX])
+{
+    // !GENERIC: every job of the launch has a power-of-two block width >= 4 (or one block per row), so
+    // the NPX pixels of a lane share the origin and no integer division is compiled in
+    const int x0 = GENERIC ? block_origin(x, bw0, bw0_shift) : ((x >> bw0_shift) << bw0_shift);
+    if (!GENERIC || NPX == 1 || block_origin(x + NPX - 1, bw0, bw0_shift) == x0) {
+        const PerspBase b = persp_base(M, x0, y);
+        const double x1 = (double)(x - x0);
+#ifndef DR3_WARP_EXACT_ONLY
+        if (fast) {
+            const double S = 262144.0;                    // 32 * 2^13
+            PerspFast f; f.X0s = b.X0 * S; f.Y0s = b.Y0 * S; f.M0s = M[0] * S; f.M3s = M[3] * S;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i)
+                if (!persp_tap_fast(M, b, f, x1 + (double)i, t[i])) t[i] = persp_tap(M, b, x1 + (double)i);
+            return;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) t[i] = persp_tap(M, b, x1 + (double)i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int xi0 = block_origin(x + i, bw0, bw0_shift);
+            t[i] = persp_tap(M, persp_base(M, xi0, y), (double)(x + i - xi0));
+        }
+    }
+}
+
 __device__ __forceinline__ void weights_32f(int fx, int fy, float w[4])
 {
     const float x1 = (float)fx * (1.f / 32), x0 = 1.f - x1, y1 = (float)fy * (1.f / 32), y0 = 1.f - y1;
     w[0] = y0 * x0; w[1] = y0 * x1; w[2] = y1 * x0; w[3] = y1 * x1;
 }
+
+// Wave tile: LX lanes along x (each PXT pixels wide) by LY = 64 / LX rows; a block stacks 4 waves in y.
+#ifndef DR3_WT4_LOG
+#define DR3_WT4_LOG 4      // 4-pixel lanes: 64 x 4 pixel wave tile, 64 x 16 block (OpenCV's own block shape)
+#endif
+#ifndef DR3_WT1_LOG
+#define DR3_WT1_LOG 6      // 1-pixel lanes
+#endif
+template <int PXT> struct WaveTile;
+template <> struct WaveTile<4> { static constexpr int LOG_LX = DR3_WT4_LOG, LX = 1 << LOG_LX, LY = 64 >> LOG_LX; };
+template <> struct WaveTile<1> { static constexpr int LOG_LX = DR3_WT1_LOG, LX = 1 << LOG_LX, LY = 64 >> LOG_LX; };
 
 template <int TYPE> struct PixelTraits;
 template <> struct PixelTraits<DR3HIP_8UC1>  { static constexpr int CN = 1, PXT = 4; };
@@ -63,186 +148,264 @@ template <> struct PixelTraits<DR3HIP_8UC4>  { static constexpr int CN = 4, PXT 
 template <> struct PixelTraits<DR3HIP_32FC1> { static constexpr int CN = 1, PXT = 1; };
 template <> struct PixelTraits<DR3HIP_32FC4> { static constexpr int CN = 4, PXT = 1; };
 
-__device__ __forceinline__ uint32_t blend_8u(int v0, int v1, int v2, int v3, const int w[4])
+// ---- 8-bit bilinear blend ------------------------------------------------------------------------
+// OpenCV: (v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with the 15-bit table w = 32 * a,
+// a = {(32-fx)(32-fy), fx(32-fy), (32-fx)fy, fx fy}; the (0,0) entry is (32767,0,0,1) after the table's
+// saturation + sum repair and still yields v0.  32*S + 2^14 = 32*(S + 2^9), so the result is
+// (S + 512) >> 10 with S = (32-fy) * h0 + fy * h1, h = (32-fx) * v_left + fx * v_right  (integers
+// distribute exactly).  h is one v_dot4_u32_u8 on bytes gathered by v_perm_b32; the vertical
+// weights are pre-multiplied by 64 so that the result is byte 2 of the accumulator (no shift; h can be
+// 32 * 255 + 16 and the weights 2048, both inside the 24-bit multiplier).
+struct Blend8 { uint32_t wlo, whi, wy0, wy1; };   // (32-fx | fx<<8), the same <<16, 64*(32-fy), 64*fy
+
+__device__ __forceinline__ Blend8 blend8_weights(int fx, int fy)
 {
-    return (uint32_t)((v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + (1 << 14)) >> 15);
+    Blend8 b;
+    b.wlo = (uint32_t)(32 - fx) | ((uint32_t)fx << 8);
+    b.whi = b.wlo << 16;
+    b.wy0 = (uint32_t)(32 - fy) << 6;
+    b.wy1 = (uint32_t)fy << 6;
+    return b;
+}
+// The rounding constant rides in the dot4 accumulators: wy0 + wy1 = 64 * 32 always, so adding 16 to both
+// horizontal sums adds 16 * 2048 = 2^15 to the vertical sum and the vertical stage is v_mul_u32_u24 +
+// v_mad_u32_u24.  (No inline asm here: gfx950 needs wait states between a DOT write and a dependent VALU
+// read, which the compiler only inserts for instructions it can see.)
+#define DR3_HROUND 16u
+__device__ __forceinline__ uint32_t blend8_vert(uint32_t h0, uint32_t h1, const Blend8& b)
+{
+    return __umul24(h0, b.wy0) + __umul24(h1, b.wy1);
+}
+// p = [top-left, top-right, bottom-left, bottom-right] bytes; returns the accumulator, result in byte 2
+__device__ __forceinline__ uint32_t blend8_quad(uint32_t p, const Blend8& b)
+{
+    return blend8_vert(__builtin_amdgcn_udot4(p, b.wlo, DR3_HROUND, false), __builtin_amdgcn_udot4(p, b.whi, DR3_HROUND, false), b);
+}
+// p = [left, right, left', right'] bytes of ONE row for two channels; returns both horizontal sums
+__device__ __forceinline__ void blend8_row2(uint32_t p, const Blend8& b, uint32_t& h, uint32_t& hp)
+{
+    h  = __builtin_amdgcn_udot4(p, b.wlo, DR3_HROUND, false);
+    hp = __builtin_amdgcn_udot4(p, b.whi, DR3_HROUND, false);
+}
+__device__ __forceinline__ uint32_t byte2(uint32_t acc) { return (acc >> 16) & 0xffu; }
+
+// per-tap checked byte fetch (border 0)
+__device__ __forceinline__ uint32_t quad_checked(gcu8 __restrict__ src, int sw, int sh, int sstride,
+                                                 int sx, int sy, int cn, int c)
+{
+    const bool x0ok = (unsigned)sx < (unsigned)sw, x1ok = (unsigned)(sx + 1) < (unsigned)sw;
+    const bool y0ok = (unsigned)sy < (unsigned)sh, y1ok = (unsigned)(sy + 1) < (unsigned)sh;
+    gcu8 r0 = src + (long long)sy * sstride + (long long)sx * cn + c;
+    gcu8 r1 = r0 + sstride;
+    const uint32_t v0 = (x0ok && y0ok) ? r0[0] : 0u, v1 = (x1ok && y0ok) ? r0[cn] : 0u;
+    const uint32_t v2 = (x0ok && y1ok) ? r1[0] : 0u, v3 = (x1ok && y1ok) ? r1[cn] : 0u;
+    return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
 }
 
-// One destination pixel.  out: CN bytes (8-bit types, low bytes of out[0..]) or CN floats.
-template <int TYPE>
-__device__ __forceinline__ void sample(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
-                                       const Tap t, uint32_t out[4])
-{
-    using P = PixelTraits<TYPE>;
-    const int sx = t.sx, sy = t.sy;
-    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {      // all four taps outside: border 0
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = 0;
-        return;
-    }
-    const bool interior = sx >= 0 && sy >= 0 && sx + 1 < sw && sy + 1 < sh;
-    const uint8_t* r0 = src + (long long)sy * sstride;
-    const uint8_t* r1 = r0 + sstride;
+// 8UC3 interior fast path, split in two so that a lane can have the loads of all its pixels in flight
+// before the first blend: pixels sx..sx+3 exist on rows sy, sy+1, so three aligned dwords per row
+// (bytes 3sx&~3 .. +11) stay inside the row.
+struct Rows3 { uint32_t a0, a1, a2, b0, b1, b2, o; };
 
-    if (TYPE == DR3HIP_32FC4) {
-        float w[4]; weights_32f(t.fx, t.fy, w);
-        float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-        if (interior) {
-            v0 = reinterpret_cast<const float4*>(r0)[sx];     v1 = reinterpret_cast<const float4*>(r0)[sx + 1];
-            v2 = reinterpret_cast<const float4*>(r1)[sx];     v3 = reinterpret_cast<const float4*>(r1)[sx + 1];
+__device__ __forceinline__ bool interior_8uc3(const Tap t, int sw, int sh)
+{
+    return (unsigned)t.sx < (unsigned)(sw - 3) && (unsigned)t.sy < (unsigned)(sh - 1);
+}
+__device__ __forceinline__ Rows3 load_8uc3(gcu8 __restrict__ src, int sstride, const Tap t)
+{
+    // 32-bit offsets from the uniform base (src_aligned guarantees stride < 2^24 and image bytes < 2^31)
+    const uint32_t bo = 3u * (uint32_t)t.sx;
+    const uint32_t off = __umul24((uint32_t)t.sy, (uint32_t)sstride) + (bo & ~3u);
+    const DR3_G uint32_t* q0 = gcast<uint32_t>(src + off);
+    const DR3_G uint32_t* q1 = gcast<uint32_t>(src + (off + (uint32_t)sstride));
+    Rows3 r;
+    r.a0 = q0[0]; r.a1 = q0[1]; r.a2 = q0[2];
+    r.b0 = q1[0]; r.b1 = q1[1]; r.b2 = q1[2];
+    r.o = bo & 3u;
+    return r;
+}
+__device__ __forceinline__ void blend_8uc3(const Rows3& r, const Tap t, uint32_t& aB, uint32_t& aG, uint32_t& aR)
+{
+    const Blend8 b = blend8_weights(t.fx, t.fy);
+    // t0 = [B0 G0 R0 B1], t1 = [G1 R1 . .] of the top row; u0, u1 of the bottom row
+    const uint32_t t0 = __builtin_amdgcn_alignbyte(r.a1, r.a0, r.o), t1 = __builtin_amdgcn_alignbyte(r.a2, r.a1, r.o);
+    const uint32_t u0 = __builtin_amdgcn_alignbyte(r.b1, r.b0, r.o), u1 = __builtin_amdgcn_alignbyte(r.b2, r.b1, r.o);
+    aB = blend8_quad(__builtin_amdgcn_perm(u0, t0, 0x07040300u), b);           // [B0 B1 B0' B1']
+    uint32_t hG0, hR0, hG1, hR1;
+    blend8_row2(__builtin_amdgcn_perm(t1, t0, 0x05020401u), b, hG0, hR0);      // [G0 G1 R0 R1]
+    blend8_row2(__builtin_amdgcn_perm(u1, u0, 0x05020401u), b, hG1, hR1);
+    aG = blend8_vert(hG0, hG1, b);
+    aR = blend8_vert(hR0, hR1, b);
+}
+
+// One 8UC3 destination pixel anywhere -> accumulators of B, G, R (result = byte 2 of each).
+__device__ __forceinline__ void pixel_8uc3(gcu8 __restrict__ src, int sw, int sh, int sstride, bool src_aligned,
+                                           const Tap t, uint32_t& aB, uint32_t& aG, uint32_t& aR)
+{
+    if (src_aligned && interior_8uc3(t, sw, sh)) { blend_8uc3(load_8uc3(src, sstride, t), t, aB, aG, aR); return; }
+    if (t.sx >= sw || t.sx + 1 < 0 || t.sy >= sh || t.sy + 1 < 0) { aB = aG = aR = 0u; return; }
+    const Blend8 b = blend8_weights(t.fx, t.fy);
+    aB = blend8_quad(quad_checked(src, sw, sh, sstride, t.sx, t.sy, 3, 0), b);
+    aG = blend8_quad(quad_checked(src, sw, sh, sstride, t.sx, t.sy, 3, 1), b);
+    aR = blend8_quad(quad_checked(src, sw, sh, sstride, t.sx, t.sy, 3, 2), b);
+}
+
+__device__ __forceinline__ uint32_t pixel_8uc1(gcu8 __restrict__ src, int sw, int sh, int sstride, const Tap t)
+{
+    if (t.sx >= sw || t.sx + 1 < 0 || t.sy >= sh || t.sy + 1 < 0) return 0u;
+    return blend8_quad(quad_checked(src, sw, sh, sstride, t.sx, t.sy, 1, 0), blend8_weights(t.fx, t.fy));
+}
+
+// 4 adjacent destination pixels of an 8UC1 / 8UC3 row, gathered and stored (dword stores when the
+// row is 4-byte aligned and all 4 pixels exist).
+template <int TYPE>
+__device__ __forceinline__ void quad_8u(gcu8 __restrict__ src, int sw, int sh, int sstride,
+                                        gu8 __restrict__ dst, int dw, int dstride, int x, int y, const Tap t[4])
+{
+    constexpr int CN = PixelTraits<TYPE>::CN;
+    // dword-aligned rows and 24/31-bit offset arithmetic: the precondition of the interior fast path
+    const bool src_aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)sstride) & 3) == 0 &&
+                             sstride < (1 << 24) && sh < (1 << 24) && (long long)sstride * sh < (1LL << 31);
+    const bool dst_aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dstride) & 3) == 0;
+    gu8 row = dst + (long long)y * dstride + (long long)x * CN;
+    const bool full = x + 3 < dw;
+    if (CN == 3) {
+        uint32_t aB[4], aG[4], aR[4];
+        if (full && src_aligned && interior_8uc3(t[0], sw, sh) && interior_8uc3(t[1], sw, sh) &&
+            interior_8uc3(t[2], sw, sh) && interior_8uc3(t[3], sw, sh)) {
+            // the common case: all 24 dword loads of the lane are issued before the first blend
+            Rows3 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = load_8uc3(src, sstride, t[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) blend_8uc3(r[i], t[i], aB[i], aG[i], aR[i]);
         } else {
-            const bool x0ok = sx >= 0, x1ok = sx + 1 < sw, y0ok = sy >= 0, y1ok = sy + 1 < sh;
-            if (x0ok && y0ok) v0 = reinterpret_cast<const float4*>(r0)[sx];
-            if (x1ok && y0ok) v1 = reinterpret_cast<const float4*>(r0)[sx + 1];
-            if (x0ok && y1ok) v2 = reinterpret_cast<const float4*>(r1)[sx];
-            if (x1ok && y1ok) v3 = reinterpret_cast<const float4*>(r1)[sx + 1];
-        }
-        out[0] = __float_as_uint(v0.x * w[0] + v1.x * w[1] + v2.x * w[2] + v3.x * w[3]);
-        out[1] = __float_as_uint(v0.y * w[0] + v1.y * w[1] + v2.y * w[2] + v3.y * w[3]);
-        out[2] = __float_as_uint(v0.z * w[0] + v1.z * w[1] + v2.z * w[2] + v3.z * w[3]);
-        out[3] = __float_as_uint(v0.w * w[0] + v1.w * w[1] + v2.w * w[2] + v3.w * w[3]);
-        return;
-    }
-    if (TYPE == DR3HIP_32FC1) {
-        float w[4]; weights_32f(t.fx, t.fy, w);
-        const bool x0ok = sx >= 0, x1ok = sx + 1 < sw, y0ok = sy >= 0, y1ok = sy + 1 < sh;
-        const float v0 = (x0ok && y0ok) ? reinterpret_cast<const float*>(r0)[sx] : 0.f;
-        const float v1 = (x1ok && y0ok) ? reinterpret_cast<const float*>(r0)[sx + 1] : 0.f;
-        const float v2 = (x0ok && y1ok) ? reinterpret_cast<const float*>(r1)[sx] : 0.f;
-        const float v3 = (x1ok && y1ok) ? reinterpret_cast<const float*>(r1)[sx + 1] : 0.f;
-        out[0] = __float_as_uint(v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]);
-        return;
-    }
-
-    int w[4]; weights_8u(t.fx, t.fy, w);
-    if (TYPE == DR3HIP_8UC4) {
-        const bool x0ok = sx >= 0, x1ok = sx + 1 < sw, y0ok = sy >= 0, y1ok = sy + 1 < sh;
-        const uint32_t v0 = (x0ok && y0ok) ? reinterpret_cast<const uint32_t*>(r0)[sx] : 0u;
-        const uint32_t v1 = (x1ok && y0ok) ? reinterpret_cast<const uint32_t*>(r0)[sx + 1] : 0u;
-        const uint32_t v2 = (x0ok && y1ok) ? reinterpret_cast<const uint32_t*>(r1)[sx] : 0u;
-        const uint32_t v3 = (x1ok && y1ok) ? reinterpret_cast<const uint32_t*>(r1)[sx + 1] : 0u;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            out[c] = blend_8u((v0 >> (8 * c)) & 0xff, (v1 >> (8 * c)) & 0xff, (v2 >> (8 * c)) & 0xff, (v3 >> (8 * c)) & 0xff, w);
-        return;
-    }
-    if (TYPE == DR3HIP_8UC3) {
-        // fast path: pixels sx..sx+3 exist on both rows, so three aligned dwords per row stay in-row
-        if (sx >= 0 && sy >= 0 && sx + 3 < sw && sy + 1 < sh && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)sstride) & 3) == 0) {
-            const int bo = 3 * sx;
-            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(r0 + (bo & ~3));
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(r1 + (bo & ~3));
-            const int o = bo & 3;
-            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-            const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
-            // bytes o..o+3 and o+4..o+7 of each row
-            const uint32_t t0 = __builtin_amdgcn_alignbyte(a1, a0, o), t1 = __builtin_amdgcn_alignbyte(a2, a1, o);
-            const uint32_t u0 = __builtin_amdgcn_alignbyte(b1, b0, o), u1 = __builtin_amdgcn_alignbyte(b2, b1, o);
-            // pixel sx = bytes 0,1,2 ; pixel sx+1 = bytes 3,4,5
-            out[0] = blend_8u(t0 & 0xff, t0 >> 24, u0 & 0xff, u0 >> 24, w);
-            out[1] = blend_8u((t0 >> 8) & 0xff, t1 & 0xff, (u0 >> 8) & 0xff, u1 & 0xff, w);
-            out[2] = blend_8u((t0 >> 16) & 0xff, (t1 >> 8) & 0xff, (u0 >> 16) & 0xff, (u1 >> 8) & 0xff, w);
-            return;
+            for (int i = 0; i < 4; ++i) {
+                aB[i] = aG[i] = aR[i] = 0u;
+                if (full || x + i < dw) pixel_8uc3(src, sw, sh, sstride, src_aligned, t[i], aB[i], aG[i], aR[i]);
+            }
         }
-    }
-    // generic 8-bit path (8UC1, 8UC3 near borders): per-tap checks, byte loads
-    {
-        constexpr int CN = P::CN;
-        const bool x0ok = sx >= 0, x1ok = sx + 1 < sw, y0ok = sy >= 0, y1ok = sy + 1 < sh;
+        if (full && dst_aligned) {
+            // byte 2 of each accumulator -> 12 interleaved bytes
+            const uint32_t bg0 = __builtin_amdgcn_perm(aG[0], aB[0], 0x0c0c0602u), rb0 = __builtin_amdgcn_perm(aB[1], aR[0], 0x0c0c0602u);
+            const uint32_t gr1 = __builtin_amdgcn_perm(aR[1], aG[1], 0x0c0c0602u), bg2 = __builtin_amdgcn_perm(aG[2], aB[2], 0x0c0c0602u);
+            const uint32_t rb2 = __builtin_amdgcn_perm(aB[3], aR[2], 0x0c0c0602u), gr3 = __builtin_amdgcn_perm(aR[3], aG[3], 0x0c0c0602u);
+            DR3_G uint32_t* o = gcast<uint32_t>(row);
+            o[0] = bg0 | (rb0 << 16); o[1] = gr1 | (bg2 << 16); o[2] = rb2 | (gr3 << 16);
+        } else {
 #pragma unroll
-        for (int c = 0; c < CN; ++c) {
-            const int v0 = (x0ok && y0ok) ? r0[sx * CN + c] : 0;
-            const int v1 = (x1ok && y0ok) ? r0[(sx + 1) * CN + c] : 0;
-            const int v2 = (x0ok && y1ok) ? r1[sx * CN + c] : 0;
-            const int v3 = (x1ok && y1ok) ? r1[(sx + 1) * CN + c] : 0;
-            out[c] = blend_8u(v0, v1, v2, v3, w);
+            for (int i = 0; i < 4; ++i)
+                if (x + i < dw) { row[3 * i] = (uint8_t)byte2(aB[i]); row[3 * i + 1] = (uint8_t)byte2(aG[i]); row[3 * i + 2] = (uint8_t)byte2(aR[i]); }
         }
-    }
-}
-
-// write PXT pixels starting at (x, y); px[i][c] as produced by sample()
-template <int TYPE>
-__device__ __forceinline__ void store_pixels(uint8_t* __restrict__ dst, int dw, int dstride, int x, int y,
-                                             const uint32_t px[][4])
-{
-    using P = PixelTraits<TYPE>;
-    uint8_t* row = dst + (long long)y * dstride;
-    if (TYPE == DR3HIP_32FC4) {
-        uint4 v; v.x = px[0][0]; v.y = px[0][1]; v.z = px[0][2]; v.w = px[0][3];
-        reinterpret_cast<uint4*>(row)[x] = v;
-    } else if (TYPE == DR3HIP_32FC1) {
-        reinterpret_cast<uint32_t*>(row)[x] = px[0][0];
-    } else if (TYPE == DR3HIP_8UC4) {
-        reinterpret_cast<uint32_t*>(row)[x] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[0][3] << 24);
     } else {
-        constexpr int CN = P::CN;
-        const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dstride) & 3) == 0;
-        if (x + 3 < dw && aligned) {
-            uint8_t b[4 * CN];
+        uint32_t a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int c = 0; c < CN; ++c) b[i * CN + c] = (uint8_t)px[i][c];
-            uint32_t* o = reinterpret_cast<uint32_t*>(row + x * CN);
-#pragma unroll
-            for (int d = 0; d < CN; ++d)
-                o[d] = (uint32_t)b[4 * d] | ((uint32_t)b[4 * d + 1] << 8) | ((uint32_t)b[4 * d + 2] << 16) | ((uint32_t)b[4 * d + 3] << 24);
+        for (int i = 0; i < 4; ++i) a[i] = (full || x + i < dw) ? pixel_8uc1(src, sw, sh, sstride, t[i]) : 0u;
+        if (full && dst_aligned) {
+            const uint32_t lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(a[3], a[2], 0x0c0c0602u);
+            *gcast<uint32_t>(row) = lo | (hi << 16);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (x + i < dw)
-#pragma unroll
-                    for (int c = 0; c < CN; ++c) row[(x + i) * CN + c] = (uint8_t)px[i][c];
+            for (int i = 0; i < 4; ++i) if (x + i < dw) row[i] = (uint8_t)byte2(a[i]);
         }
     }
 }
 
+// ---- one pixel per lane: 8UC4, 32FC1, 32FC4 ------------------------------------------------------
 template <int TYPE>
+__device__ __forceinline__ void single_px(gcu8 __restrict__ src, int sw, int sh, int sstride,
+                                          gu8 __restrict__ dst, int dstride, int x, int y, const Tap t)
+{
+    const int sx = t.sx, sy = t.sy;
+    gu8 row = dst + (long long)y * dstride;
+    const bool outside = sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0;      // all four taps: border 0
+    const bool x0ok = sx >= 0 && !outside, x1ok = sx + 1 < sw && !outside, y0ok = sy >= 0, y1ok = sy + 1 < sh;
+    gcu8 r0 = src + (long long)sy * sstride;
+    gcu8 r1 = r0 + sstride;
+    if (TYPE == DR3HIP_32FC4) {
+        float w[4]; weights_32f(t.fx, t.fy, w);
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+        if (x0ok && y0ok) v0 = gcast<f32x4>(r0)[sx];
+        if (x1ok && y0ok) v1 = gcast<f32x4>(r0)[sx + 1];
+        if (x0ok && y1ok) v2 = gcast<f32x4>(r1)[sx];
+        if (x1ok && y1ok) v3 = gcast<f32x4>(r1)[sx + 1];
+        f32x4 o;
+        o.x = v0.x * w[0] + v1.x * w[1] + v2.x * w[2] + v3.x * w[3];
+        o.y = v0.y * w[0] + v1.y * w[1] + v2.y * w[2] + v3.y * w[3];
+        o.z = v0.z * w[0] + v1.z * w[1] + v2.z * w[2] + v3.z * w[3];
+        o.w = v0.w * w[0] + v1.w * w[1] + v2.w * w[2] + v3.w * w[3];
+        gcast<f32x4>(row)[x] = o;
+    } else if (TYPE == DR3HIP_32FC1) {
+        float w[4]; weights_32f(t.fx, t.fy, w);
+        const float v0 = (x0ok && y0ok) ? gcast<float>(r0)[sx] : 0.f;
+        const float v1 = (x1ok && y0ok) ? gcast<float>(r0)[sx + 1] : 0.f;
+        const float v2 = (x0ok && y1ok) ? gcast<float>(r1)[sx] : 0.f;
+        const float v3 = (x1ok && y1ok) ? gcast<float>(r1)[sx + 1] : 0.f;
+        gcast<float>(row)[x] = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+    } else {   // 8UC4
+        const Blend8 b = blend8_weights(t.fx, t.fy);
+        const uint32_t v0 = (x0ok && y0ok) ? gcast<uint32_t>(r0)[sx] : 0u;
+        const uint32_t v1 = (x1ok && y0ok) ? gcast<uint32_t>(r0)[sx + 1] : 0u;
+        const uint32_t v2 = (x0ok && y1ok) ? gcast<uint32_t>(r1)[sx] : 0u;
+        const uint32_t v3 = (x1ok && y1ok) ? gcast<uint32_t>(r1)[sx + 1] : 0u;
+        // channel pairs (0,1) and (2,3) of the top and the bottom row
+        uint32_t h00, h01, h02, h03, h10, h11, h12, h13;
+        blend8_row2(__builtin_amdgcn_perm(v1, v0, 0x05010400u), b, h00, h01);
+        blend8_row2(__builtin_amdgcn_perm(v1, v0, 0x07030602u), b, h02, h03);
+        blend8_row2(__builtin_amdgcn_perm(v3, v2, 0x05010400u), b, h10, h11);
+        blend8_row2(__builtin_amdgcn_perm(v3, v2, 0x07030602u), b, h12, h13);
+        const uint32_t c01 = __builtin_amdgcn_perm(blend8_vert(h01, h11, b), blend8_vert(h00, h10, b), 0x0c0c0602u);
+        const uint32_t c23 = __builtin_amdgcn_perm(blend8_vert(h03, h13, b), blend8_vert(h02, h12, b), 0x0c0c0602u);
+        gcast<uint32_t>(row)[x] = c01 | (c23 << 16);
+    }
+}
+
+template <int TYPE, bool GENERIC>
 __global__ __launch_bounds__(256) void warp_perspective_kernel(const WarpJobDev* __restrict__ jobs)
 {
     using P = PixelTraits<TYPE>;
     const WarpJobDev& jb = jobs[blockIdx.z];
-    const int x = (blockIdx.x * 64 + threadIdx.x) * P::PXT;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    // a wave is a 2-D tile of the destination (WaveTile<PXT>): the source lines its lanes gather from are
+    // then shared inside the wave and with the 3 waves below it instead of being spread over 256 columns
+    using WT = WaveTile<P::PXT>;
+    const int x = (blockIdx.x * WT::LX + (threadIdx.x & (WT::LX - 1))) * P::PXT;
     const int dw = jb.dw, dh = jb.dh;
-    if (x >= dw || y >= dh) return;
-    const int bw0 = jb.bw0;
-    const int bw0_shift = (bw0 & (bw0 - 1)) == 0 ? __builtin_ctz(bw0) : -1;
+    if (x >= dw) return;
+    const int bw0 = jb.bw0, bw0_shift = jb.bw0_shift;
     double M[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
 
-    uint32_t px[P::PXT][4];
-#pragma unroll
-    for (int i = 0; i < P::PXT; ++i) {
-        if (x + i < dw) {
-            const Tap t = persp_tap(M, bw0, bw0_shift, x + i, y);
-            sample<TYPE>(jb.src, jb.sw, jb.sh, jb.sstride, t, px[i]);
-        }
+    {
+        const int y = (blockIdx.y * 4 + threadIdx.y) * WT::LY + (threadIdx.x >> WT::LOG_LX);
+        if (y >= dh) return;
+        Tap t[P::PXT];
+        persp_taps<P::PXT, GENERIC>(M, bw0, bw0_shift, jb.fast != 0, x, y, t);
+        if (P::PXT == 4) quad_8u<TYPE>((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, (gu8)jb.dst, dw, jb.dstride, x, y, t);
+        else             single_px<TYPE>((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, (gu8)jb.dst, jb.dstride, x, y, t[0]);
     }
-    store_pixels<TYPE>(jb.dst, dw, jb.dstride, x, y, px);
 }
 
 template <int TYPE>
 __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
 {
     using P = PixelTraits<TYPE>;
-    const int x = (blockIdx.x * 64 + threadIdx.x) * P::PXT;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    using WT = WaveTile<P::PXT>;
+    const int x = (blockIdx.x * WT::LX + (threadIdx.x & (WT::LX - 1))) * P::PXT;
+    const int y = (blockIdx.y * 4 + threadIdx.y) * WT::LY + (threadIdx.x >> WT::LOG_LX);
     if (x >= a.dw || y >= a.dh) return;
     const float* mx = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapx) + (long long)y * a.map_stride);
     const float* my = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapy) + (long long)y * a.map_stride);
-    uint32_t px[P::PXT][4];
+    Tap t[P::PXT];
 #pragma unroll
     for (int i = 0; i < P::PXT; ++i) {
-        if (x + i < a.dw) {
-            // cvRound(mapx * INTER_TAB_SIZE): f32 multiply, round half to even
-            const int sx = __float2int_rn(mx[x + i] * 32.f), sy = __float2int_rn(my[x + i] * 32.f);
-            Tap t; t.sx = sat_s16(sx >> 5); t.sy = sat_s16(sy >> 5); t.fx = sx & 31; t.fy = sy & 31;
-            sample<TYPE>(a.src, a.sw, a.sh, a.sstride, t, px[i]);
-        }
+        t[i] = tap_from_fixed(0, 0);
+        // cvRound(mapx * INTER_TAB_SIZE): f32 multiply, round half to even
+        if (x + i < a.dw) t[i] = tap_from_fixed(__float2int_rn(mx[x + i] * 32.f), __float2int_rn(my[x + i] * 32.f));
     }
-    store_pixels<TYPE>(a.dst, a.dw, a.dstride, x, y, px);
+    if (P::PXT == 4) quad_8u<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dw, a.dstride, x, y, t);
+    else             single_px<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dstride, x, y, t[0]);
 }
 
 // ---- 2x2 box half-sampler ---------------------------------------------------------------------
@@ -302,20 +465,22 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
 
 }  // namespace
 
-hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, hipStream_t s)
+hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s)
 {
     if (n_jobs <= 0 || max_dw <= 0 || max_dh <= 0) return hipSuccess;
     const int pxt = (type == DR3HIP_8UC1 || type == DR3HIP_8UC3) ? 4 : 1;
     dim3 block(64, 4);
-    dim3 grid((max_dw + 64 * pxt - 1) / (64 * pxt), (max_dh + 3) / 4, n_jobs);
+    const int tw = pxt == 4 ? WaveTile<4>::LX * 4 : WaveTile<1>::LX, th = 4 * (pxt == 4 ? WaveTile<4>::LY : WaveTile<1>::LY);
+    dim3 grid((max_dw + tw - 1) / tw, (max_dh + th - 1) / th, n_jobs);
+#define DR3_WARP_CASE(T) \
+    case T: if (generic) hipLaunchKernelGGL((warp_perspective_kernel<T, true>),  grid, block, 0, s, d_jobs); \
+            else         hipLaunchKernelGGL((warp_perspective_kernel<T, false>), grid, block, 0, s, d_jobs); break;
     switch (type) {
-    case DR3HIP_8UC1:  hipLaunchKernelGGL((warp_perspective_kernel<DR3HIP_8UC1>),  grid, block, 0, s, d_jobs); break;
-    case DR3HIP_8UC3:  hipLaunchKernelGGL((warp_perspective_kernel<DR3HIP_8UC3>),  grid, block, 0, s, d_jobs); break;
-    case DR3HIP_8UC4:  hipLaunchKernelGGL((warp_perspective_kernel<DR3HIP_8UC4>),  grid, block, 0, s, d_jobs); break;
-    case DR3HIP_32FC1: hipLaunchKernelGGL((warp_perspective_kernel<DR3HIP_32FC1>), grid, block, 0, s, d_jobs); break;
-    case DR3HIP_32FC4: hipLaunchKernelGGL((warp_perspective_kernel<DR3HIP_32FC4>), grid, block, 0, s, d_jobs); break;
+    DR3_WARP_CASE(DR3HIP_8UC1) DR3_WARP_CASE(DR3HIP_8UC3) DR3_WARP_CASE(DR3HIP_8UC4)
+    DR3_WARP_CASE(DR3HIP_32FC1) DR3_WARP_CASE(DR3HIP_32FC4)
     default: return hipErrorInvalidValue;
     }
+#undef DR3_WARP_CASE
     return hipGetLastError();
 }
 
@@ -324,7 +489,8 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
     if (a.dw <= 0 || a.dh <= 0) return hipSuccess;
     const int pxt = (type == DR3HIP_8UC1 || type == DR3HIP_8UC3) ? 4 : 1;
     dim3 block(64, 4);
-    dim3 grid((a.dw + 64 * pxt - 1) / (64 * pxt), (a.dh + 3) / 4, 1);
+    const int tw = pxt == 4 ? WaveTile<4>::LX * 4 : WaveTile<1>::LX, th = 4 * (pxt == 4 ? WaveTile<4>::LY : WaveTile<1>::LY);
+    dim3 grid((a.dw + tw - 1) / tw, (a.dh + th - 1) / th, 1);
     switch (type) {
     case DR3HIP_8UC1:  hipLaunchKernelGGL((remap_kernel<DR3HIP_8UC1>),  grid, block, 0, s, a); break;
     case DR3HIP_8UC3:  hipLaunchKernelGGL((remap_kernel<DR3HIP_8UC3>),  grid, block, 0, s, a); break;

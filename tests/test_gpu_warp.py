@@ -48,6 +48,36 @@ def test_warp_identity_and_integer_translation(dr3, O, ctx):
     assert np.array_equal(ctx.warpPerspective(src, M, (100, 80)), O.warp_perspective(src, M, (100, 80)))
 
 
+def test_warp_rounding_ties_and_fast_path_guard(dr3, O, ctx):
+    """source coordinates that land exactly on (or a hair beside) the 1/64-px rounding ties of the 1/32-px
+    grid: the kernel's fast coordinate path must hand every such pixel to the exact f64 sequence"""
+    rng = np.random.default_rng(21)
+    src = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    for k in range(1, 64, 6):                                          # odd k: every pixel is an exact tie
+        for eps in (0.0, 2.0 ** -20, -2.0 ** -20):
+            M = np.array([[1, 0, k / 64 + eps], [0, 1, (64 - k) / 64 - eps], [0, 0, 1]], np.float32)
+            for flags in (0, dr3.WARP_INVERSE_MAP):
+                assert np.array_equal(ctx.warpPerspective(src, M, (140, 100), flags),
+                                      O.warp_perspective(src, M, (140, 100), flags)), (k, eps, flags)
+    # ties under a perspective divide: W = 1 + x/1024 exactly representable
+    M = np.array([[1, 0, 0.015625], [0, 1, 0.046875], [1 / 1024, 0, 1]], np.float32)
+    assert np.array_equal(ctx.warpPerspective(src, M, (256, 100), dr3.WARP_INVERSE_MAP),
+                          O.warp_perspective(src, M, (256, 100), O.WARP_INVERSE_MAP))
+    gray = src[..., 0].copy()
+    M = np.array([[0.5, 0, 0.25], [0, 2, 0.5], [0, 0, 1]], np.float32)
+    assert np.array_equal(ctx.warpPerspective(gray, M, (90, 120)), O.warp_perspective(gray, M, (90, 120)))
+
+
+def test_warp_large_tile_random_homographies(dr3, O, ctx, synth):
+    """1500x1100 8UC3 tiles (tens of millions of coordinates, so thousands pass through the tie guard)"""
+    rng = np.random.default_rng(22)
+    src = rng.integers(0, 256, (1100, 1500, 3), dtype=np.uint8)
+    for k in range(3):
+        M = synth.tile_homography(k, 1500, 1100)
+        M[0, 2] -= 30; M[1, 2] -= 30
+        assert np.array_equal(ctx.warpPerspective(src, M, (1500, 1100)), O.warp_perspective(src, M, (1500, 1100))), k
+
+
 def test_warp_small_and_degenerate(dr3, O, ctx):
     """dst smaller than one 16x64 block, singular-ish / far-outside maps -> zeros like the oracle"""
     rng = np.random.default_rng(4)

@@ -1,0 +1,12 @@
+"""warp leg of bench.py alone (configs[2]); prints kernel ms and roofline fraction per type"""
+import importlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (one HIP runtime per process, as in bench.py)
+import bench
+dr3 = importlib.import_module("3dr_amd")
+synth = importlib.import_module("3dr_amd.synth")
+dist = bench.Dist(1, backend=None)
+ctx = dr3.Context(0)
+r = bench.warp_leg(dist, ctx, dr3, synth, ctx.sync, steps=10)
+print(" ".join("%s %.4f ms frac %.3f" % (k, v["kernel_ms"], v["roofline"]["frac"]) for k, v in r.items() if isinstance(v, dict)), sys.argv[1:] and sys.argv[1] or "")
+ctx.close()
