@@ -30,6 +30,7 @@ CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
 PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0 = 0, 1, 2, 3, 4, 5
+COMM_ID_BYTES = 128
 
 
 class Dr3HipError(RuntimeError):
@@ -104,6 +105,13 @@ def _signatures():
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
+        "dr3hip_comm_unique_id": ([vp, vp], ip),
+        "dr3hip_comm_init": ([vp, vp, ip, ip], ip),
+        "dr3hip_comm_destroy": ([vp], ip),
+        "dr3hip_comm_world": ([vp], ip),
+        "dr3hip_comm_rank": ([vp], ip),
+        "dr3hip_bcast": ([vp, vp, C.c_size_t, ip], ip),
+        "dr3hip_batch_bcast_slot": ([vp, ip, ip, ip], C.c_longlong),
         "dr3hip_timer_start": ([vp], ip),
         "dr3hip_timer_stop": ([vp, fp_], ip),
         "dr3hip_profile_enable": ([vp, ip], ip),
@@ -226,6 +234,26 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    # ---- multi-GPU: RCCL broadcast (include/dr3hip.h "multi-GPU") -----------------------------
+    def comm_unique_id(self):
+        """root only: the 128 bytes every rank passes to comm_init"""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self._chk(lib().dr3hip_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._chk(lib().dr3hip_comm_init(self.h, C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), int(world), int(rank)))
+
+    def comm_destroy(self):
+        self._chk(lib().dr3hip_comm_destroy(self.h))
+
+    def comm_world(self):
+        return lib().dr3hip_comm_world(self.h)
+
+    def bcast(self, buf, nbytes, root=0):
+        self._chk(lib().dr3hip_bcast(self.h, buf.ptr if isinstance(buf, DeviceBuffer) else buf, int(nbytes), int(root)))
+
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
@@ -345,6 +373,10 @@ class FrameBatch:
 
     def build(self, first, count, with_deriv=True):
         self.ctx._chk(lib().dr3hip_batch_build(self.h, first, count, int(with_deriv)))
+
+    def bcast_slot(self, slot, root=0, with_deriv=True):
+        """RCCL broadcast of one slot's pyramid (+ derivative pyramid) from `root`; returns bytes moved"""
+        return self.ctx._chk(lib().dr3hip_batch_bcast_slot(self.h, int(slot), int(root), int(with_deriv)))
 
     def download_image(self, slot, level):
         li = self.level_info(level)

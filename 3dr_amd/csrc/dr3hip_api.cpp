@@ -4,6 +4,7 @@
 // like cv::invert does on the reference's x86-64 build).
 #include "dr3hip_internal.h"
 #include <cmath>
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +31,8 @@ struct dr3hip_ctx {
     int prof_n[DR3HIP_PROF_SLOTS] = {0};
     std::vector<ProfEvent> pending;
     std::vector<hipEvent_t> ev_pool;      // recycled events: no hipEventCreate in the steady state
+    void* comm = nullptr;                 // ncclComm_t (RCCL), see "multi-GPU" below
+    int comm_world = 0, comm_rank = -1;
 };
 
 struct dr3hip_batch {
@@ -158,6 +161,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     prof_drain(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
+    (void)dr3hip_comm_destroy(ctx);
     for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -216,6 +220,122 @@ int dr3hip_memset(dr3hip_ctx* ctx, void* dst, int value, size_t bytes)
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return DR3HIP_OK;
+}
+
+// ---- multi-GPU: RCCL broadcast --------------------------------------------------------------
+// librccl is resolved with dlopen on first use: libdr3hip.so has no link-time dependency on it, and a
+// process that already carries an RCCL (PyTorch bundles one under the same SONAME) shares that copy.
+namespace {
+struct RcclId128 { char b[128]; };          // ncclUniqueId: NCCL_UNIQUE_ID_BYTES = 128, passed by value
+struct Rccl {
+    void* h = nullptr;
+    int  (*GetUniqueId)(void*) = nullptr;
+    int  (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
+    int  (*CommDestroy)(void*) = nullptr;
+    int  (*Broadcast)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void*, hipStream_t) = nullptr;
+    int  (*GroupStart)() = nullptr;
+    int  (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl g_rccl;
+
+bool rccl_load()
+{
+    if (g_rccl.h) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { g_rccl.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return false; }
+#define DR3_SYM(field, name) \
+    *(void**)(&g_rccl.field) = dlsym(h, name); \
+    if (!g_rccl.field) { g_rccl.err = std::string("librccl lacks ") + name; dlclose(h); return false; }
+    DR3_SYM(GetUniqueId, "ncclGetUniqueId") DR3_SYM(CommInitRank, "ncclCommInitRank") DR3_SYM(CommDestroy, "ncclCommDestroy")
+    DR3_SYM(Broadcast, "ncclBroadcast") DR3_SYM(GroupStart, "ncclGroupStart") DR3_SYM(GroupEnd, "ncclGroupEnd")
+    DR3_SYM(GetErrorString, "ncclGetErrorString")
+#undef DR3_SYM
+    g_rccl.h = h;
+    return true;
+}
+const int kNcclUint8 = 1;     // ncclUint8 / ncclChar family: ncclInt8 = 0, ncclUint8 = 1 (rccl.h)
+}  // namespace
+
+#define NCCLCHK(ctx, call)                                                                       \
+    do { int r_ = (call);                                                                         \
+         if (r_ != 0) return fail((ctx), DR3HIP_EHIP, "%s: %s", #call, g_rccl.GetErrorString(r_)); } while (0)
+
+int dr3hip_comm_unique_id(dr3hip_ctx* ctx, void* id128)
+{
+    if (!ctx || !id128) return DR3HIP_EINVAL;
+    if (!rccl_load()) return fail(ctx, DR3HIP_ENODEV, "%s", g_rccl.err.c_str());
+    NCCLCHK(ctx, g_rccl.GetUniqueId(id128));
+    return DR3HIP_OK;
+}
+
+int dr3hip_comm_init(dr3hip_ctx* ctx, const void* id128, int world, int rank)
+{
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, DR3HIP_EINVAL, "comm_init: bad arguments");
+    if (ctx->comm) return fail(ctx, DR3HIP_EINVAL, "comm_init: this context already has a communicator");
+    if (!rccl_load()) return fail(ctx, DR3HIP_ENODEV, "%s", g_rccl.err.c_str());
+    DeviceGuard g(ctx->device);
+    RcclId128 id; memcpy(id.b, id128, sizeof(id.b));
+    void* comm = nullptr;
+    NCCLCHK(ctx, g_rccl.CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm; ctx->comm_world = world; ctx->comm_rank = rank;
+    return DR3HIP_OK;
+}
+
+int dr3hip_comm_destroy(dr3hip_ctx* ctx)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!ctx->comm) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr; ctx->comm_world = 0; ctx->comm_rank = -1;
+    return DR3HIP_OK;
+}
+
+int dr3hip_comm_world(const dr3hip_ctx* ctx) { return ctx ? ctx->comm_world : 0; }
+int dr3hip_comm_rank(const dr3hip_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
+
+int dr3hip_bcast(dr3hip_ctx* ctx, void* dptr, size_t bytes, int root)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!ctx->comm) return fail(ctx, DR3HIP_EINVAL, "bcast: no communicator (dr3hip_comm_init)");
+    if (!dptr || root < 0 || root >= ctx->comm_world) return fail(ctx, DR3HIP_EINVAL, "bcast: bad arguments");
+    if (bytes == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    NCCLCHK(ctx, g_rccl.Broadcast(dptr, dptr, bytes, kNcclUint8, root, ctx->comm, ctx->stream));
+    return DR3HIP_OK;
+}
+
+long long dr3hip_batch_bcast_slot(dr3hip_batch* b, int slot, int root, int with_deriv)
+{
+    if (!b) return DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    if (!ctx->comm) return fail(ctx, DR3HIP_EINVAL, "batch_bcast_slot: no communicator (dr3hip_comm_init)");
+    if (slot < 0 || slot >= b->capacity || root < 0 || root >= ctx->comm_world) return fail(ctx, DR3HIP_EINVAL, "batch_bcast_slot: bad slot/root");
+    DeviceGuard g(ctx->device);
+    long long moved = 0;
+    NCCLCHK(ctx, g_rccl.GroupStart());
+    for (int l = 0; l < b->levels; ++l) {
+        const LevelDev& v = b->lv[l];
+        // whole rows including the pitch slack: the receiver's plane becomes byte-identical to the root's
+        uint8_t* pi = v.img + (size_t)v.step * slot;
+        const size_t ib = (size_t)v.pitch * v.h;
+        int r = g_rccl.Broadcast(pi, pi, ib, kNcclUint8, root, ctx->comm, ctx->stream);
+        moved += (long long)ib;
+        if (r == 0 && with_deriv) {
+            uint8_t* pd = (uint8_t*)v.der + (size_t)v.dstep * slot;
+            const size_t db = (size_t)v.dpitch * v.h;
+            r = g_rccl.Broadcast(pd, pd, db, kNcclUint8, root, ctx->comm, ctx->stream);
+            moved += (long long)db;
+        }
+        if (r != 0) { (void)g_rccl.GroupEnd(); return fail(ctx, DR3HIP_EHIP, "ncclBroadcast (level %d): %s", l, g_rccl.GetErrorString(r)); }
+    }
+    NCCLCHK(ctx, g_rccl.GroupEnd());
+    return moved;
 }
 
 // ---- timing ---------------------------------------------------------------------------------------

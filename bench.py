@@ -73,6 +73,14 @@ class Dist:
         self.dist.broadcast(t, src=0)
         return tuple(float(v) for v in t.cpu().tolist())
 
+    def bcast_bytes(self, payload, n):
+        """rank 0's `n` bytes to every rank over the torch.distributed group (bootstrap of the RCCL id)"""
+        if not self.pg:
+            return bytes(payload)
+        t = self.torch.tensor(list(payload) if self.rank == 0 else [0] * n, dtype=self.torch.uint8, device=self.device)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().tolist())
+
     def max_over_ranks(self, x):
         if not self.pg:
             return float(x)
@@ -201,7 +209,9 @@ def main(argv=None):
     import torch
     # DR3_BENCH_BACKEND=gloo rehearses the N>1 protocol on a box with fewer GPUs than ranks (the ranks then
     # share devices; RCCL refuses two ranks on one GPU).  The driver's runs use the default, nccl == RCCL.
-    backend = os.environ.get("DR3_BENCH_BACKEND", "nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
+    # DR3_BENCH_FORCE_PG=1 runs the process-group code (RCCL id hand-over, broadcast leg) even at world size 1.
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DR3_BENCH_FORCE_PG") == "1"
+    backend = os.environ.get("DR3_BENCH_BACKEND", "nccl") if multi else None
     dist = Dist(args.gpus, backend=backend)
     dr3 = importlib.import_module("3dr_amd")
     synth = importlib.import_module("3dr_amd.synth")
@@ -230,6 +240,43 @@ def main(argv=None):
     # slot 0 stands for the frame carried over from the previous batch of the stream.  Build it with a
     # full-size launch so that every launch rocprofv3 averages for this kernel has the same shape.
     batch.build(0, B + 1, True)
+
+    # ---- RCCL broadcast of a reference frame's pyramid through the library's own communicator
+    # (untimed; N > 1 over real GPUs only -- RCCL refuses ranks that share a device).  A failure is reported
+    # in the JSON line, it does not void the throughput measurement, which needs no collective.
+    ref_bcast = None
+    if dist.pg and backend == "nccl":
+        # every torch.distributed call below runs on every rank whatever happened locally, so a rank that
+        # failed cannot leave the others waiting in a collective
+        err, moved, ms, got = None, 0, 0.0, 0.0
+        try:
+            uid_root = ctx.comm_unique_id() if dist.rank == 0 else b"\0" * dr3.COMM_ID_BYTES
+        except Exception as e:                                   # noqa: BLE001
+            uid_root, err = b"\0" * dr3.COMM_ID_BYTES, str(e)
+        uid = dist.bcast_bytes(uid_root, dr3.COMM_ID_BYTES)
+        if dist.max_over_ranks(1.0 if err else 0.0) == 0.0:      # the root has an id: all ranks enter the init
+            try:
+                ctx.comm_init(uid, dist.world, dist.rank)
+                if dist.rank != 0:                               # receivers start from zeroed planes
+                    batch.upload(0, np.zeros_like(frames[0])); batch.build(0, 1, True)
+                sync()
+                ctx.timer_start()
+                moved = batch.bcast_slot(0, root=0, with_deriv=True)
+                ms = ctx.timer_stop()
+                got = float(batch.download_image(0, levels - 1).astype(np.int64).sum()
+                            + np.abs(batch.download_deriv(0, 0).astype(np.int64)).sum())
+                ctx.comm_destroy()
+            except Exception as e:                               # noqa: BLE001 -- reported, not fatal
+                err = str(e)
+        n_err = dist.sum_over_ranks(1.0 if err else 0.0)
+        hi, lo, ms_max = dist.max_over_ranks(got), -dist.max_over_ranks(-got), dist.max_over_ranks(ms)
+        ref_bcast = {"bytes_per_rank": int(moved), "ms": ms_max, "identical_on_all_ranks": bool(n_err == 0 and hi == lo),
+                     "transport": "RCCL ncclBroadcast x %d in one group (dr3hip_batch_bcast_slot)" % (2 * levels),
+                     "ranks_with_error": int(n_err), "error": (err or "")[:300] or None}
+        if dist.rank != 0:                                       # put this rank's own frame 0 back
+            batch.upload(0, frames[0])
+        batch.build(0, 1, True)
+        sync()
 
     def step():
         batch.build(1, B, True)                                  # pyramid + gradient pass, B new frames
@@ -314,6 +361,7 @@ def main(argv=None):
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "latency/issue-bound, not HBM-bound (SURVEY 8d): no roofline fraction claimed"},
             "warp": warp,
+            "ref_pyramid_bcast": ref_bcast,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -189,6 +189,28 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
 int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
                           uint8_t* d_dst, int dstride, int mode);
 
+/* ---- multi-GPU: one process per GPU, one ctx per process --------------------------- */
+/* The path shards by independent frame pairs / canvas tiles, so there is no reduction and no
+ * exchange; the only collective is a broadcast from the rank that owns the shared state: the camera
+ * intrinsics (reference tests/test_pipeline.cpp:62-64) and, for the one-keyframe-vs-many-candidates
+ * pattern, the reference frame's Gaussian pyramid + Scharr derivative pyramid (5 S bytes) built
+ * once by the root.  Transport is RCCL over xGMI (librccl is dlopen'ed on first use, so single-GPU
+ * users never load it).  Bootstrap: the root calls dr3hip_comm_unique_id, the host side hands the
+ * 128 bytes to every rank by any means (the bench uses its torch.distributed store), then every rank
+ * calls dr3hip_comm_init with the same id.  Collectives are enqueued on the ctx stream. */
+#define DR3HIP_COMM_ID_BYTES 128
+int dr3hip_comm_unique_id(dr3hip_ctx* ctx, void* id128);
+int dr3hip_comm_init(dr3hip_ctx* ctx, const void* id128, int world, int rank);
+int dr3hip_comm_destroy(dr3hip_ctx* ctx);
+int dr3hip_comm_world(const dr3hip_ctx* ctx);                 /* 0 when no communicator */
+int dr3hip_comm_rank(const dr3hip_ctx* ctx);
+/* broadcast `bytes` device bytes from rank `root` (in place on every rank) */
+int dr3hip_bcast(dr3hip_ctx* ctx, void* dptr, size_t bytes, int root);
+/* broadcast every level of slot `slot` (image plane, and derivative plane when with_deriv) from
+ * `root` into the same slot of every rank's batch (same geometry on all ranks): 2 (L+1) broadcasts
+ * fused in one RCCL group.  Returns the bytes moved per rank, or < 0. */
+long long dr3hip_batch_bcast_slot(dr3hip_batch* b, int slot, int root, int with_deriv);
+
 /* ---- timing ------------------------------------------------------------------------------- */
 /* hipEvent pair on the ctx stream (the stream the kernels run on). */
 int dr3hip_timer_start(dr3hip_ctx* ctx);

@@ -68,3 +68,35 @@ def test_extreme_images(dr3, O, ctx):
         assert np.abs(b.download_deriv(3, 0)).max() == 16 * 255
     finally:
         b.close()
+
+
+def test_rccl_ref_pyramid_broadcast_world1(dr3, O, synth):
+    """the reference-pyramid broadcast through the C ABI's RCCL communicator.  One GPU per box,
+    so world = 1 here: this pins symbol resolution, the id hand-over, group semantics and that the root's
+    planes are left byte-identical; the N > 1 protocol is rehearsed with gloo in tests/test_dist.py."""
+    A, _, _ = synth.frame_pair(320, 200)
+    with dr3.Context(0) as ctx:
+        fb = dr3.FrameBatch(ctx, 320, 200, win=(15, 15), max_level=3, capacity=2)
+        fb.upload(0, A)
+        fb.build(0, 1, True)
+        ctx.sync()
+        before = [(fb.download_image(0, l), fb.download_deriv(0, l)) for l in range(fb.levels)]
+        ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        assert ctx.comm_world() == 1
+        moved = fb.bcast_slot(0, root=0, with_deriv=True)
+        ctx.sync()
+        want = sum(fb.level_info(l).img_pitch * fb.level_info(l).h + fb.level_info(l).der_pitch * fb.level_info(l).h
+                   for l in range(fb.levels))
+        assert moved == want
+        for l, (img, der) in enumerate(before):
+            assert np.array_equal(fb.download_image(0, l), img) and np.array_equal(fb.download_deriv(0, l), der), l
+        intr = ctx.to_device(np.array([718.856, 718.856, 607.1928, 185.2157, 1241, 376], np.float64))
+        ctx.bcast(intr, 48, root=0)
+        ctx.sync()
+        assert intr.download((6,), np.float64)[4] == 1241
+        with pytest.raises(dr3.Dr3HipError):
+            fb.bcast_slot(5, root=0)            # slot out of range
+        ctx.comm_destroy()
+        with pytest.raises(dr3.Dr3HipError):
+            fb.bcast_slot(0, root=0)            # no communicator
+        intr.free(); fb.close()
