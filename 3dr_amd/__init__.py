@@ -29,7 +29,7 @@ WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
-PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0 = 0, 1, 2, 3, 4, 5
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM = 0, 1, 2, 3, 4, 5, 6, 7
 COMM_ID_BYTES = 128
 
 
@@ -105,6 +105,10 @@ def _signatures():
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
+        "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
+        "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
+        "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
+        "dr3hip_panorama_normalize": ([vp, vp, ip, ip, ip, vp, ip], ip),
         "dr3hip_comm_unique_id": ([vp, vp], ip),
         "dr3hip_comm_init": ([vp, vp, ip, ip], ip),
         "dr3hip_comm_destroy": ([vp], ip),
@@ -233,6 +237,38 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    # ---- panorama paste (reference src/panorama.cpp:156-229) -----------------------------------
+    def panorama_add(self, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, feathering_width):
+        """device-resident Panorama::add_img_to_canvas (fused warp + feather + accumulate)"""
+        M = np.ascontiguousarray(M, np.float32).reshape(9)
+        ptr = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
+        self._chk(lib().dr3hip_panorama_add(self.h, ptr(d_img), w, h, istride, ptr(d_canvas), cw, ch, cstride,
+                                            _p(M), int(feathering_width)))
+
+    def panorama_normalize(self, d_canvas, cw, ch, cstride, d_out, ostride):
+        ptr = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
+        self._chk(lib().dr3hip_panorama_normalize(self.h, ptr(d_canvas), cw, ch, cstride, ptr(d_out), ostride))
+
+    def paste_images(self, images, Ms, canvas_size, feathering_width):
+        """Panorama::paste_images + normalize_canvas (src/panorama.cpp:143-154, :215-229) for host images:
+        returns (weighted canvas (H, W, 4) f32, panorama (H, W, 3) u8).  Ms are the forward homographies
+        already multiplied by top_left, as at :148."""
+        cw, ch = canvas_size
+        d_canvas = self.alloc(cw * ch * 16)
+        d_canvas.zero()
+        d_out = self.alloc(cw * ch * 3)
+        try:
+            for img, M in zip(images, Ms):
+                img = np.ascontiguousarray(img, np.uint8)
+                d_img = self.to_device(img)
+                self.panorama_add(d_img, img.shape[1], img.shape[0], img.strides[0], d_canvas, cw, ch, cw * 16, M, feathering_width)
+                self.sync()
+                d_img.free()
+            self.panorama_normalize(d_canvas, cw, ch, cw * 16, d_out, cw * 3)
+            return d_canvas.download((ch, cw, 4), np.float32), d_out.download((ch, cw, 3), np.uint8)
+        finally:
+            d_canvas.free(); d_out.free()
 
     # ---- multi-GPU: RCCL broadcast (include/dr3hip.h "multi-GPU") -----------------------------
     def comm_unique_id(self):
@@ -409,3 +445,22 @@ def warp_batch(ctx, jobs, img_type, flags=0):
         for k in range(9):
             arr[i].M[k] = float(M[k])
     ctx._chk(lib().dr3hip_warp_perspective_batch(ctx.h, arr, len(jobs), int(img_type), int(flags)))
+
+
+def panorama_bbox(M, w, h):
+    """Panorama::set_bbox (src/panorama.cpp:112-138), host-only -> (min_x, min_y, max_x, max_y)"""
+    M = np.ascontiguousarray(M, np.float32).reshape(9)
+    o = [C.c_int() for _ in range(4)]
+    rc = lib().dr3hip_panorama_bbox(_p(M), int(w), int(h), *[C.byref(v) for v in o])
+    if rc != 0:
+        raise Dr3HipError("dr3hip_panorama_bbox failed (%d)" % rc)
+    return tuple(v.value for v in o)
+
+
+def panorama_ramp(min_x, max_x, feathering_width):
+    """feather vector of add_img_to_canvas (src/panorama.cpp:163-177), host-only"""
+    ramp = np.zeros(max(max_x - min_x, 1), np.float32)
+    n = lib().dr3hip_panorama_ramp(int(min_x), int(max_x), int(feathering_width), _p(ramp))
+    if n < 0:
+        raise Dr3HipError("dr3hip_panorama_ramp: the reference throws for this box (%d)" % n)
+    return ramp[:n]

@@ -3,6 +3,7 @@
 // Compiled by hipcc as host code (-ffp-contract=off: the homography inversion below must round
 // like cv::invert does on the reference's x86-64 build).
 #include "dr3hip_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <dlfcn.h>
 
@@ -24,7 +25,7 @@ struct dr3hip_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // grow-only staging buffers for the host-buffer calls
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf stage[6];
+    Buf stage[7];
     dr3hip_batch* lk_batch = nullptr;     // cached 2-slot batch behind dr3hip_lk_track
     bool prof = false;
     double prof_ms[DR3HIP_PROF_SLOTS] = {0};
@@ -219,6 +220,97 @@ int dr3hip_memset(dr3hip_ctx* ctx, void* dst, int value, size_t bytes)
     if (!ctx || (bytes && !dst)) return DR3HIP_EINVAL;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return DR3HIP_OK;
+}
+
+// ---- panorama paste -------------------------------------------------------------------------
+static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
+                     const float M[9], int flags);      // defined with the warp entry points below
+
+int dr3hip_panorama_bbox(const float M[9], int w, int h, int* min_x, int* min_y, int* max_x, int* max_y)
+{
+    if (!M || !min_x || !min_y || !max_x || !max_y) return DR3HIP_EINVAL;
+    // src/panorama.cpp:117-124: corners (0,0,1), (w,0,1), (0,h,1), (w,h,1); (M * corners^T)^T is one CV_32F
+    // gemm, which accumulates float products in double and rounds once
+    const float cx[4] = {0.f, (float)w, 0.f, (float)w}, cy[4] = {0.f, 0.f, (float)h, (float)h};
+    float X[4], Y[4];
+    for (int i = 0; i < 4; ++i) {
+        float t[3];
+        for (int r = 0; r < 3; ++r)
+            t[r] = (float)((double)M[3 * r] * (double)cx[i] + (double)M[3 * r + 1] * (double)cy[i] + (double)M[3 * r + 2] * 1.0);
+        X[i] = t[0] / t[2];                                               // :126-130
+        Y[i] = t[1] / t[2];
+    }
+    *min_x = (int)*std::min_element(X, X + 4); *min_y = (int)*std::min_element(Y, Y + 4);      // :138-141
+    *max_x = (int)*std::max_element(X, X + 4); *max_y = (int)*std::max_element(Y, Y + 4);
+    return DR3HIP_OK;
+}
+
+static void linspace_ref(float a, float b, int n, float* out)            // include/utils.hpp:37-46
+{
+    const float h = (b - a) / (float)(n - 1);
+    float val = a;
+    for (int i = 0; i < n; ++i) { out[i] = val; val += h; }
+}
+
+int dr3hip_panorama_ramp(int min_x, int max_x, int feathering_width, float* ramp)
+{
+    if (!ramp) return DR3HIP_EINVAL;
+    const int n = max_x - min_x;
+    int temp = feathering_width;                                          // :166-170
+    if (n - 2 * feathering_width < 0) temp = n / 2 - 1;
+    const int mid = n - 2 * temp;
+    if (temp < 0 || mid < 0) return DR3HIP_EINVAL;                        // size_t(-1) elements: the reference throws
+    linspace_ref(0.f, 1.f, temp, ramp);                                   // :172-177
+    for (int i = 0; i < mid; ++i) ramp[temp + i] = 1.0f;
+    linspace_ref(1.f, 0.f, temp, ramp + temp + mid);
+    return n;
+}
+
+int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
+                        float* d_canvas, int cw, int ch, int cstride, const float M[9], int feathering_width)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_img || !d_canvas || !M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || cstride < 16 * cw)
+        return fail(ctx, DR3HIP_EINVAL, "panorama_add: bad arguments");
+    if ((((uintptr_t)d_canvas | (uintptr_t)cstride) & 15) != 0) return fail(ctx, DR3HIP_EINVAL, "panorama_add: canvas rows must be 16-byte aligned");
+    int min_x, min_y, max_x, max_y;
+    dr3hip_panorama_bbox(M, w, h, &min_x, &min_y, &max_x, &max_y);
+    const int n = max_x - min_x;
+    if (n < 2 || n > (1 << 24)) return fail(ctx, DR3HIP_EINVAL, "panorama_add: bounding box of %d columns (the reference throws below 2)", n);
+    std::vector<float> ramp((size_t)n);
+    if (dr3hip_panorama_ramp(min_x, max_x, feathering_width, ramp.data()) != n)
+        return fail(ctx, DR3HIP_EINVAL, "panorama_add: feathering width %d does not fit a %d-column box", feathering_width, n);
+    DeviceGuard g(ctx->device);
+    int rc;
+    if ((rc = stage_reserve(ctx, 6, sizeof(float) * (size_t)n))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[6].p, ramp.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                       // ramp is a local
+    WarpJobDev j;                                                         // the :192 warp: dst = the whole canvas
+    make_job(j, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, 0);
+    PanoAddArgs a;
+    a.img = d_img; a.w = w; a.h = h; a.istride = istride;
+    a.canvas = d_canvas; a.cw = cw; a.ch = ch; a.cstride = cstride;
+    for (int i = 0; i < 9; ++i) a.M[i] = j.M[i];
+    a.bw0 = j.bw0; a.bw0_shift = j.bw0_shift; a.fast = j.fast;
+    a.cx0 = min_x < 0 ? 0 : min_x; a.cx1 = max_x > cw ? cw : max_x; a.min_x = min_x;
+    a.ramp = (const float*)ctx->stage[6].p;
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PANO_ADD, pe);
+    HIPCHK(ctx, launch_panorama_add(a, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_panorama_normalize(dr3hip_ctx* ctx, const float* d_canvas, int cw, int ch, int cstride, uint8_t* d_out, int ostride)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_canvas || !d_out || cw < 1 || ch < 1 || cstride < 16 * cw || ostride < 3 * cw || (((uintptr_t)d_canvas | (uintptr_t)cstride) & 15) != 0)
+        return fail(ctx, DR3HIP_EINVAL, "panorama_normalize: bad arguments");
+    DeviceGuard g(ctx->device);
+    PanoNormArgs a; a.canvas = d_canvas; a.cw = cw; a.ch = ch; a.cstride = cstride; a.out = d_out; a.ostride = ostride;
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PANO_NORM, pe);
+    HIPCHK(ctx, launch_panorama_normalize(a, ctx->stream));
+    prof_end(ctx, pe);
     return DR3HIP_OK;
 }
 

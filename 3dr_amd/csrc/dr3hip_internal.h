@@ -62,6 +62,20 @@ struct WarpJobDev {
     int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191)
 };
 
+struct PanoAddArgs {       // fused Panorama::add_img_to_canvas (src/panorama.cpp:178-212)
+    const uint8_t* img; int w, h, istride;        // 8UC3 source image
+    float* canvas;      int cw, ch, cstride;      // 32FC4 weighted canvas (read-modify-write)
+    double M[9];        int bw0, bw0_shift, fast; // inverse map + WarpPerspectiveInvoker block split, as WarpJobDev
+    int cx0, cx1;                                 // canvas columns [cx0, cx1) = [min_x, max_x) clipped to the canvas
+    int min_x;                                    // ramp[x - min_x]
+    const float* ramp;                            // device, max_x - min_x entries
+};
+
+struct PanoNormArgs {      // Panorama::normalize_canvas (src/panorama.cpp:215-229)
+    const float* canvas; int cw, ch, cstride;
+    uint8_t* out;        int ostride;
+};
+
 struct RemapArgs {
     const uint8_t* src; int sw, sh, sstride;
     uint8_t* dst;       int dw, dh, dstride;
@@ -80,6 +94,8 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
+hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
+hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 
 // geometry helpers shared by host and launchers
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }

@@ -408,6 +408,96 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
     else             single_px<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dstride, x, y, t[0]);
 }
 
+// ---- fused panorama paste -----------------------------------------------------------------
+// reconstruct::Panorama::add_img_to_canvas, reference src/panorama.cpp:178-212, in one pass over the
+// bounding-box columns of the canvas: the reference builds a (B,G,R,1) 32FC4 copy of the image, warps it
+// onto a canvas-sized 32FC4 image (:192), then walks the columns [min_x, max_x) scaling BGR by the feather
+// ramp, setting alpha to the ramp, dropping pixels whose scaled BGR is exactly 0 and adding the rest to the
+// canvas.  Here one lane warps one canvas pixel straight from the 8UC3 image (u8 -> f32 is exact, so the
+// taps equal the 32FC4 copy's), with the 32FC4 arithmetic of the warp (f32 table weights, 4-term sum, no
+// FMA), multiplies by ramp[x - min_x] and does the 16-byte read-modify-write.  Bytes per canvas pixel in
+// the box: 3 read (image) + 16 + 16 (canvas) instead of 16 + 16 (warp) + 32 + 32 (feather pass).
+template <bool GENERIC>
+__global__ __launch_bounds__(256) void panorama_add_kernel(const PanoAddArgs a)
+{
+    const int x = a.cx0 + blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.cx1 || y >= a.ch) return;
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = a.M[i];
+    Tap t[1];
+    persp_taps<1, GENERIC>(M, a.bw0, a.bw0_shift, a.fast != 0, x, y, t);
+    const int sx = t[0].sx, sy = t[0].sy, sw = a.w, sh = a.h;
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return;      // every tap is border 0: scaled BGR == 0
+    gcu8 src = (gcu8)a.img;
+    const bool src_aligned = ((reinterpret_cast<uintptr_t>(a.img) | (uintptr_t)a.istride) & 3) == 0 &&
+                             a.istride < (1 << 24) && sh < (1 << 24) && (long long)a.istride * sh < (1LL << 31);
+    uint32_t pB, pG, pR;          // [top-left, top-right, bottom-left, bottom-right] bytes per channel
+    if (src_aligned && interior_8uc3(t[0], sw, sh)) {
+        const Rows3 r = load_8uc3(src, a.istride, t[0]);
+        const uint32_t t0 = __builtin_amdgcn_alignbyte(r.a1, r.a0, r.o), t1 = __builtin_amdgcn_alignbyte(r.a2, r.a1, r.o);
+        const uint32_t u0 = __builtin_amdgcn_alignbyte(r.b1, r.b0, r.o), u1 = __builtin_amdgcn_alignbyte(r.b2, r.b1, r.o);
+        pB = __builtin_amdgcn_perm(u0, t0, 0x07040300u);
+        const uint32_t gr0 = __builtin_amdgcn_perm(t1, t0, 0x05020401u), gr1 = __builtin_amdgcn_perm(u1, u0, 0x05020401u);   // [G0 G1 R0 R1]
+        pG = __builtin_amdgcn_perm(gr1, gr0, 0x05040100u);
+        pR = __builtin_amdgcn_perm(gr1, gr0, 0x07060302u);
+    } else {
+        pB = quad_checked(src, sw, sh, a.istride, sx, sy, 3, 0);
+        pG = quad_checked(src, sw, sh, a.istride, sx, sy, 3, 1);
+        pR = quad_checked(src, sw, sh, a.istride, sx, sy, 3, 2);
+    }
+    float w[4]; weights_32f(t[0].fx, t[0].fy, w);
+    const float r = a.ramp[x - a.min_x];
+    float o[3];
+    const uint32_t p[3] = {pB, pG, pR};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v0 = (float)(p[c] & 0xffu), v1 = (float)((p[c] >> 8) & 0xffu), v2 = (float)((p[c] >> 16) & 0xffu), v3 = (float)(p[c] >> 24);
+        o[c] = (v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]) * r;
+    }
+    if (o[0] == 0.f && o[1] == 0.f && o[2] == 0.f) return;               // :205-207
+    DR3_G f32x4* cp = reinterpret_cast<DR3_G f32x4*>((gu8)reinterpret_cast<uint8_t*>(a.canvas) + (long long)y * a.cstride) + x;
+    f32x4 c4 = *cp;
+    c4.x += o[0]; c4.y += o[1]; c4.z += o[2]; c4.w += r;
+    *cp = c4;
+}
+
+// Panorama::normalize_canvas, reference src/panorama.cpp:215-229: vec[c] = (int)canvas[c] / alpha_sum
+// (int cast first, f32 divide, then narrowing to uchar), pixels with alpha_sum <= 0 stay 0.
+__global__ __launch_bounds__(256) void panorama_normalize_kernel(const PanoNormArgs a)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.cw || y >= a.ch) return;
+    const DR3_G f32x4* cp = reinterpret_cast<const DR3_G f32x4*>((gcu8)reinterpret_cast<const uint8_t*>(a.canvas) + (long long)y * a.cstride) + x;
+    uint32_t px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        px[i] = 0u;
+        if (x + i < a.cw) {
+            const f32x4 c4 = cp[i];
+            if (c4.w > 0.0f) {
+                const uint32_t b = (uint32_t)(int)((float)(int)c4.x / c4.w) & 0xffu;
+                const uint32_t g = (uint32_t)(int)((float)(int)c4.y / c4.w) & 0xffu;
+                const uint32_t r = (uint32_t)(int)((float)(int)c4.z / c4.w) & 0xffu;
+                px[i] = b | (g << 8) | (r << 16);
+            }
+        }
+    }
+    gu8 row = (gu8)a.out + (long long)y * a.ostride + (long long)x * 3;
+    if (x + 3 < a.cw && ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.ostride) & 3) == 0) {
+        DR3_G uint32_t* o = gcast<uint32_t>(row);
+        o[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);
+        o[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
+        o[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x + i < a.cw) { row[3 * i] = (uint8_t)px[i]; row[3 * i + 1] = (uint8_t)(px[i] >> 8); row[3 * i + 2] = (uint8_t)(px[i] >> 16); }
+    }
+}
+
 // ---- 2x2 box half-sampler ---------------------------------------------------------------------
 __device__ __forceinline__ uint32_t half_px(int a, int b, int c, int d, int mode)
 {
@@ -499,6 +589,25 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
     case DR3HIP_32FC4: hipLaunchKernelGGL((remap_kernel<DR3HIP_32FC4>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s)
+{
+    if (a.cx1 <= a.cx0 || a.ch <= 0) return hipSuccess;
+    dim3 block(64, 4);
+    dim3 grid((a.cx1 - a.cx0 + 63) / 64, (a.ch + 3) / 4, 1);
+    if (a.bw0_shift < 0) hipLaunchKernelGGL(panorama_add_kernel<true>,  grid, block, 0, s, a);
+    else                 hipLaunchKernelGGL(panorama_add_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s)
+{
+    if (a.cw <= 0 || a.ch <= 0) return hipSuccess;
+    dim3 block(64, 4);
+    dim3 grid((a.cw + 255) / 256, (a.ch + 3) / 4, 1);
+    hipLaunchKernelGGL(panorama_normalize_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

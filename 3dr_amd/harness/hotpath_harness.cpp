@@ -128,6 +128,16 @@ int main(int argc, char** argv)
             }
         wr(fo, final_panorama.data(), final_panorama.size());
 
+        // ---- (2b) the same paste as the library's fused device path: paste_images (:143-154) keeps the
+        // weighted canvas on the GPU, add_img_to_canvas is one kernel, normalize_canvas another
+        {
+            dr3hip::WeightedCanvas weighted_canvas(dr3hip::Size(W, H));       // :144
+            weighted_canvas.add_img_to_canvas(dr3hip::MatView(img.data(), th, tw, (size_t)tw * 3, DR3HIP_8UC3), M, feather);   // :149
+            dr3hip::Image fused_panorama;
+            weighted_canvas.normalize(fused_panorama);                          // :67
+            wr(fo, fused_panorama.buf.data(), fused_panorama.buf.size());
+        }
+
         // ---- (3) Frame constructor pyramid ------------------------------------------------------
         std::vector<dr3hip::Image> pyr;
         dr3hip::create_img_pyramid(mref, 3, pyr);                              // src/frame.cpp:18, n_pyr_levels = 3 (src/config.cpp)

@@ -413,7 +413,61 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
         for d in srcs + dsts:
             d.free()
     res["workload"] = "configs[2]: 8 tiles 4000x3000, per-pixel homography, bilinear, border 0"
+    res["paste"] = paste_leg(dist, ctx, dr3, synth, sync, tile, steps)
     return res
+
+
+def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
+    """configs[2] as the reference really runs it (Panorama::paste_images, src/panorama.cpp:143-154): the 8 tiles
+    are pasted into ONE 32FC4 weighted canvas (4 x 2 layout, ~10 % overlap, feathering width 300) by the fused
+    warp + feather + accumulate kernel, then normalised to 8UC3.  One step = 8 pastes + 1 normalise."""
+    TH_, TW_ = tile.shape[:2]
+    Ms = []
+    for i in range(8):
+        M = synth.tile_homography(i, TW_, TH_).astype(np.float64)
+        T = np.eye(3); T[0, 2] = (i % 4) * TW_ * 0.9 + 100; T[1, 2] = (i // 4) * TH_ * 0.9 + 150
+        Ms.append((T @ M).astype(np.float32))
+    boxes = [dr3.panorama_bbox(M, TW_, TH_) for M in Ms]
+    cw = (max(b[2] for b in boxes) + 64) // 64 * 64
+    ch = max(b[3] for b in boxes) + 16
+    d_img = ctx.to_device(tile)
+    d_canvas = ctx.alloc(cw * ch * 16)
+    d_out = ctx.alloc(cw * ch * 3)
+    box_px = sum((min(b[2], cw) - max(b[0], 0)) * ch for b in boxes)
+
+    def step():
+        d_canvas.zero()
+        for M in Ms:
+            ctx.panorama_add(d_img, TW_, TH_, TW_ * 3, d_canvas, cw, ch, cw * 16, M, 300)
+        ctx.panorama_normalize(d_canvas, cw, ch, cw * 16, d_out, cw * 3)
+
+    ctx.profile_enable(True)
+    step(); sync()
+    ctx.profile_reset()
+    el = timed_region(dist, step, sync, steps, 0)
+    ms_add, n_add = ctx.profile_read(dr3.PROF_PANO_ADD)
+    ms_norm, n_norm = ctx.profile_read(dr3.PROF_PANO_NORM)
+    ctx.profile_enable(False)
+    for d in (d_img, d_canvas, d_out):
+        d.free()
+    add_ms = ms_add / max(n_add, 1)                      # per paste
+    # algorithmic bytes of one paste: every canvas pixel of the box is warped (3 B of source per covered pixel)
+    # and, where covered by the tile, read + written (16 + 16 B); covered ~ tile area
+    alg_add = TW_ * TH_ * (3 + 32)
+    alg_norm = cw * ch * (16 + 3)
+    norm_ms = ms_norm / max(n_norm, 1)
+    return {"canvas": [cw, ch], "tiles": 8, "feathering_width": 300,
+            "tile_mpix_per_s": aggregate_rate(dist, 8 * TW_ * TH_ * steps / 1e6, el),
+            "step_ms": el / steps * 1e3,
+            "add_kernel_ms": add_ms, "box_pixels_per_step": box_px,
+            "roofline_add": {"kernel": "panorama_add_kernel", "bound": "hbm", "achieved": alg_add / (add_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_add / (add_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "traffic": None, "algorithmic_bytes_per_launch": alg_add},
+            "roofline_normalize": {"kernel": "panorama_normalize_kernel", "bound": "hbm", "achieved": alg_norm / (norm_ms * 1e-3) / 1e9,
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_norm / (norm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": alg_norm, "kernel_ms": norm_ms},
+            "replaces": "reference passes per tile: 32FC4 copy (3 r + 16 w), warp onto the full canvas (16 r + 16 w per canvas px), "
+                        "feather + accumulate (32 r + 32 w per box px)"}
 
 
 def host_cores():

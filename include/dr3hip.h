@@ -189,6 +189,25 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
 int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
                           uint8_t* d_dst, int dstride, int mode);
 
+/* ---- panorama paste: reconstruct::Panorama, reference src/panorama.cpp ------------- */
+/* Panorama::set_bbox (src/panorama.cpp:112-138): bounding box of the image corners under the forward
+ * f32 homography M, truncated with int().  Host-only. */
+int dr3hip_panorama_bbox(const float M[9], int w, int h, int* min_x, int* min_y, int* max_x, int* max_y);
+/* The feather vector of add_img_to_canvas (src/panorama.cpp:163-177), max_x - min_x entries, built with
+ * the reference's accumulating utils::linspace (include/utils.hpp:37-46).  Returns the entry count, or
+ * DR3HIP_EINVAL where the reference itself throws (a box narrower than 2 columns).  Host-only. */
+int dr3hip_panorama_ramp(int min_x, int max_x, int feathering_width, float* ramp);
+/* Panorama::add_img_to_canvas (src/panorama.cpp:156-212) fused into one kernel: warps the 8UC3 device
+ * image d_img (as the (B,G,R,1) 32FC4 image the reference builds) onto the 32FC4 device canvas through the
+ * forward homography M (= top_left * H, as at :148), feathers with the ramp and accumulates.  Columns
+ * outside [0, cw) are skipped (the reference indexes them unchecked). */
+int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
+                        float* d_canvas, int cw, int ch, int cstride,
+                        const float M[9], int feathering_width);
+/* Panorama::normalize_canvas (src/panorama.cpp:215-229): 32FC4 weighted canvas -> 8UC3 panorama. */
+int dr3hip_panorama_normalize(dr3hip_ctx* ctx, const float* d_canvas, int cw, int ch, int cstride,
+                              uint8_t* d_out, int ostride);
+
 /* ---- multi-GPU: one process per GPU, one ctx per process --------------------------- */
 /* The path shards by independent frame pairs / canvas tiles, so there is no reduction and no
  * exchange; the only collective is a broadcast from the rank that owns the shared state: the camera
@@ -223,7 +242,9 @@ int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on 
 #define DR3HIP_PROF_REMAP   3
 #define DR3HIP_PROF_HALF    4
 #define DR3HIP_PROF_PYR_L0  5   /* the level-0 fused pyrDown+Scharr kernel alone (dominant HBM kernel) */
-#define DR3HIP_PROF_SLOTS   6
+#define DR3HIP_PROF_PANO_ADD  6 /* fused panorama paste kernel                                        */
+#define DR3HIP_PROF_PANO_NORM 7
+#define DR3HIP_PROF_SLOTS   8
 int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
 int dr3hip_profile_reset(dr3hip_ctx* ctx);

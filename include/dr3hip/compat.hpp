@@ -6,6 +6,8 @@
 //     cv::warpPerspective        src/stitch.cpp:73-74, src/panorama.cpp:192 -> dr3hip::warpPerspective
 //     cv::remap                  src/utils.cpp:191                -> dr3hip::remap
 //     utils::create_img_pyramid  src/utils.cpp:421-430 (src/frame.cpp:18) -> dr3hip::create_img_pyramid
+//     Panorama::paste_images / add_img_to_canvas / normalize_canvas  src/panorama.cpp:143-229
+//                                                                 -> dr3hip::WeightedCanvas
 // Images travel as MatView {data, rows, cols, step, type}: a plain view that a cv::Mat converts to
 // with MatView::of(mat) where OpenCV exists (define DR3HIP_WITH_OPENCV before including), so
 // include/features.hpp, include/stitch.hpp and include/panorama.hpp of the reference stay untouched.
@@ -188,6 +190,58 @@ inline void create_img_pyramid(const MatView& img_lvl_0, int n_levels, std::vect
     c.check(dr3hip_halfsample_pyramid(c.get(), static_cast<const uint8_t*>(img_lvl_0.data), img_lvl_0.cols, img_lvl_0.rows,
                                       (int)img_lvl_0.step, n_levels, mode, ptrs.data(), strides.data()), "create_img_pyramid");
 }
+
+// reconstruct::Panorama::paste_images / add_img_to_canvas / normalize_canvas (src/panorama.cpp:143-229).
+// The reference's `cv::Mat weighted_panorama` (CV_32FC4, zeros(_W x _H), :144) becomes a device-resident
+// canvas: add_img_to_canvas(img, M, feathering_width) is the fused warp + feather + accumulate kernel,
+// normalize() is normalize_canvas into an 8UC3 Image (the reference's _final_panorama).
+class WeightedCanvas {
+public:
+    WeightedCanvas(Size size, int device = 0) : c_(Context::instance(device)), W_(size.width), H_(size.height), canvas_(nullptr) {
+        if (W_ < 1 || H_ < 1) throw Error(DR3HIP_EINVAL, "WeightedCanvas: empty canvas");
+        void* p = nullptr;
+        c_.check(dr3hip_malloc(c_.get(), (std::size_t)W_ * H_ * 16, &p), "WeightedCanvas");
+        canvas_ = static_cast<float*>(p);
+        c_.check(dr3hip_memset(c_.get(), canvas_, 0, (std::size_t)W_ * H_ * 16), "WeightedCanvas");
+    }
+    ~WeightedCanvas() { if (canvas_) dr3hip_free(c_.get(), canvas_); }
+    Size size() const { return Size(W_, H_); }
+    // Panorama::add_img_to_canvas(img, M, feathering_width, weighted_panorama): img 8UC3, M = top_left * H (f32)
+    void add_img_to_canvas(const MatView& img, const float M[9], int feathering_width) {
+        if (img.empty() || img.type != DR3HIP_8UC3) throw Error(DR3HIP_EINVAL, "add_img_to_canvas: 8UC3 image expected");
+        void* d = nullptr;
+        const std::size_t pitch = ((std::size_t)img.cols * 3 + 63) / 64 * 64;
+        c_.check(dr3hip_malloc(c_.get(), pitch * img.rows, &d), "add_img_to_canvas");
+        int rc = DR3HIP_OK;
+        for (int r = 0; r < img.rows && rc == DR3HIP_OK; ++r)      // row copies keep the ABI to plain memcpy
+            rc = dr3hip_memcpy_h2d(c_.get(), static_cast<unsigned char*>(d) + pitch * r,
+                                   static_cast<const unsigned char*>(img.data) + img.step * (std::size_t)r, (std::size_t)img.cols * 3);
+        if (rc == DR3HIP_OK)
+            rc = dr3hip_panorama_add(c_.get(), static_cast<const uint8_t*>(d), img.cols, img.rows, (int)pitch,
+                                     canvas_, W_, H_, W_ * 16, M, feathering_width);
+        if (rc == DR3HIP_OK) rc = dr3hip_sync(c_.get());
+        dr3hip_free(c_.get(), d);
+        c_.check(rc, "add_img_to_canvas");
+    }
+    // Panorama::normalize_canvas(weighted_panorama) -> _final_panorama (8UC3, _W x _H)
+    void normalize(Image& final_panorama) {
+        final_panorama.create(H_, W_, DR3HIP_8UC3);
+        void* d = nullptr;
+        c_.check(dr3hip_malloc(c_.get(), (std::size_t)W_ * H_ * 3, &d), "normalize_canvas");
+        int rc = dr3hip_panorama_normalize(c_.get(), canvas_, W_, H_, W_ * 16, static_cast<uint8_t*>(d), W_ * 3);
+        if (rc == DR3HIP_OK) rc = dr3hip_memcpy_d2h(c_.get(), final_panorama.buf.data(), d, (std::size_t)W_ * H_ * 3);
+        dr3hip_free(c_.get(), d);
+        c_.check(rc, "normalize_canvas");
+    }
+    // the weighted canvas itself (tests; the reference never reads it back)
+    void download(Image& weighted) {
+        weighted.create(H_, W_, DR3HIP_32FC4);
+        c_.check(dr3hip_memcpy_d2h(c_.get(), weighted.buf.data(), canvas_, (std::size_t)W_ * H_ * 16), "WeightedCanvas::download");
+    }
+private:
+    WeightedCanvas(const WeightedCanvas&); WeightedCanvas& operator=(const WeightedCanvas&);
+    Context& c_; int W_, H_; float* canvas_;
+};
 
 }  // namespace dr3hip
 #endif  // DR3HIP_COMPAT_HPP

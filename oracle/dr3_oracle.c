@@ -708,6 +708,46 @@ void dr3o_linspace_f32(float a, float b, int n, float* out)
     for (i = 0; i < n; ++i) { out[i] = val; val += hstep; }
 }
 
+/* src/panorama.cpp:112-138 */
+void dr3o_panorama_bbox(const float M[9], int w, int h, int* min_x, int* min_y, int* max_x, int* max_y)
+{
+    const float cx[4] = {0.f, (float)w, 0.f, (float)w}, cy[4] = {0.f, 0.f, (float)h, (float)h};
+    float X[4], Y[4], mnx, mny, mxx, mxy;
+    int i;
+    for (i = 0; i < 4; ++i) {
+        /* (M * corners^T)^T: one gemm, float inputs, double accumulation, one rounding to float */
+        float t[3];
+        int r;
+        for (r = 0; r < 3; ++r)
+            t[r] = (float)((double)M[3 * r] * (double)cx[i] + (double)M[3 * r + 1] * (double)cy[i] + (double)M[3 * r + 2] * 1.0);
+        X[i] = t[0] / t[2];
+        Y[i] = t[1] / t[2];
+    }
+    mnx = mxx = X[0]; mny = mxy = Y[0];
+    for (i = 1; i < 4; ++i) {                      /* std::min_element / max_element: first extreme, '<' */
+        if (X[i] < mnx) mnx = X[i];
+        if (mxx < X[i]) mxx = X[i];
+        if (Y[i] < mny) mny = Y[i];
+        if (mxy < Y[i]) mxy = Y[i];
+    }
+    *min_x = (int)mnx; *min_y = (int)mny; *max_x = (int)mxx; *max_y = (int)mxy;
+}
+
+/* src/panorama.cpp:163-177 */
+int dr3o_feather_ramp(int min_x, int max_x, int feathering_width, float* ramp)
+{
+    const int n = max_x - min_x;
+    int temp = feathering_width, mid, i;
+    if (n - 2 * feathering_width < 0) temp = n / 2 - 1;
+    if (temp < 0) return -1;                       /* linspace(size_t(-1)) / vector(-k): the reference throws */
+    mid = n - 2 * temp;
+    if (mid < 0) return -1;
+    dr3o_linspace_f32(0.f, 1.f, temp, ramp);
+    for (i = 0; i < mid; ++i) ramp[temp + i] = 1.0f;
+    dr3o_linspace_f32(1.f, 0.f, temp, ramp + temp + mid);
+    return n;
+}
+
 /* src/panorama.cpp:194-212.  Scales BGR by the ramp, sets alpha to the ramp, drops pixels whose
  * scaled BGR is exactly (0,0,0), accumulates the rest into the canvas. */
 void dr3o_feather_accumulate(float* canvas, int cw, int ch, int cstride,
@@ -752,4 +792,30 @@ void dr3o_normalize_canvas(const float* canvas, int cw, int ch, int cstride,
             }
         }
     }
+}
+
+/* src/panorama.cpp:156-212 */
+int dr3o_panorama_add(const uint8_t* img, int w, int h, int istride, float* canvas, int cw, int ch, int cstride,
+                      const float M[9], int feathering_width, float* scratch, int n_threads)
+{
+    int min_x, min_y, max_x, max_y, n, i, j;
+    float* ramp;
+    float* wimg;
+    dr3o_panorama_bbox(M, w, h, &min_x, &min_y, &max_x, &max_y);
+    n = max_x - min_x;
+    if (n < 2) return -1;
+    ramp = (float*)malloc(sizeof(float) * (size_t)n);
+    wimg = (float*)malloc(sizeof(float) * 4 * (size_t)w * h);
+    if (!ramp || !wimg) { free(ramp); free(wimg); return -2; }
+    if (dr3o_feather_ramp(min_x, max_x, feathering_width, ramp) != n) { free(ramp); free(wimg); return -1; }
+    for (i = 0; i < h; ++i)                        /* :178-189: ones(32FC4), BGR from img.convertTo(CV_32FC3) */
+        for (j = 0; j < w; ++j) {
+            float* o = wimg + 4 * ((size_t)i * w + j);
+            const uint8_t* s = img + (size_t)i * istride + 3 * j;
+            o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = 1.0f;
+        }
+    dr3o_warp_perspective(wimg, w, h, w * 16, DR3O_32FC4, scratch, cw, ch, cw * 16, M, 0, n_threads);   /* :192 */
+    dr3o_feather_accumulate(canvas, cw, ch, cstride, scratch, cw * 16, min_x, max_x, ramp);              /* :194-212 */
+    free(ramp); free(wimg);
+    return 0;
 }

@@ -124,6 +124,17 @@ void dr3o_normalize_canvas(const float* canvas, int cw, int ch, int cstride,
                            uint8_t* out, int ostride);
 /* include/utils.hpp:37-46 */
 void dr3o_linspace_f32(float a, float b, int n, float* out);
+/* src/panorama.cpp:112-138  Panorama::set_bbox: corners (0,0),(w,0),(0,h),(w,h) through the f32 3x3 M,
+ * divided by their weight, min/max truncated with int().  The 3x4 product is a cv::gemm on CV_32F
+ * (OpenCV accumulates float products in double and rounds once -- restated so, flagged unpinned). */
+void dr3o_panorama_bbox(const float M[9], int w, int h, int* min_x, int* min_y, int* max_x, int* max_y);
+/* src/panorama.cpp:163-177: the per-column feather ramp of add_img_to_canvas; ramp gets max_x - min_x
+ * entries.  Returns that count, or -1 where the reference itself would throw (fewer than 2 columns). */
+int  dr3o_feather_ramp(int min_x, int max_x, int feathering_width, float* ramp);
+/* src/panorama.cpp:156-212 composed: 8UC3 image -> (B,G,R,1) 32FC4 -> warpPerspective onto the canvas
+ * size -> feather + accumulate.  `scratch` = cw*ch*4 floats for the warped image. */
+int  dr3o_panorama_add(const uint8_t* img, int w, int h, int istride, float* canvas, int cw, int ch, int cstride,
+                       const float M[9], int feathering_width, float* scratch, int n_threads);
 
 #ifdef __cplusplus
 }

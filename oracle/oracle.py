@@ -73,6 +73,12 @@ def lib():
         L.dr3o_normalize_canvas.restype = None
         L.dr3o_linspace_f32.argtypes = [C.c_float, C.c_float, ip, vp]
         L.dr3o_linspace_f32.restype = None
+        L.dr3o_panorama_bbox.argtypes = [vp, ip, ip, vp, vp, vp, vp]
+        L.dr3o_panorama_bbox.restype = None
+        L.dr3o_feather_ramp.argtypes = [ip, ip, ip, vp]
+        L.dr3o_feather_ramp.restype = ip
+        L.dr3o_panorama_add.argtypes = [vp, ip, ip, ip, vp, ip, ip, ip, vp, ip, vp, ip]
+        L.dr3o_panorama_add.restype = ip
         _lib = L
     return _lib
 
@@ -247,3 +253,35 @@ def normalize_canvas(canvas):
     out = np.zeros((ch, cw, 3), np.uint8)
     lib().dr3o_normalize_canvas(_p(canvas), cw, ch, canvas.strides[0], _p(out), out.strides[0])
     return out
+
+
+def panorama_bbox(M, w, h):
+    """Panorama::set_bbox (src/panorama.cpp:112-138) -> (min_x, min_y, max_x, max_y)"""
+    M = np.ascontiguousarray(M, np.float32).reshape(9)
+    out = [C.c_int() for _ in range(4)]
+    lib().dr3o_panorama_bbox(_p(M), int(w), int(h), *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def feather_ramp(min_x, max_x, feathering_width):
+    """the left/mid/right blend vector of add_img_to_canvas (src/panorama.cpp:163-177)"""
+    n = max_x - min_x
+    ramp = np.zeros(max(n, 0), np.float32)
+    r = lib().dr3o_feather_ramp(int(min_x), int(max_x), int(feathering_width), _p(ramp))
+    if r < 0:
+        raise ValueError("the reference throws for a %d-column bounding box" % n)
+    return ramp
+
+
+def panorama_add(img, canvas, M, feathering_width, n_threads=0):
+    """Panorama::add_img_to_canvas (src/panorama.cpp:156-212), canvas (H, W, 4) f32 updated in place"""
+    img = np.ascontiguousarray(img, np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3 and canvas.dtype == np.float32 and canvas.flags.c_contiguous
+    ch, cw = canvas.shape[:2]
+    M = np.ascontiguousarray(M, np.float32).reshape(9)
+    scratch = np.empty((ch, cw, 4), np.float32)
+    r = lib().dr3o_panorama_add(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(canvas), cw, ch, canvas.strides[0],
+                                _p(M), int(feathering_width), _p(scratch), int(n_threads))
+    if r != 0:
+        raise ValueError("panorama_add failed (%d)" % r)
+    return canvas

@@ -1,0 +1,78 @@
+"""Fused panorama paste on the GPU vs the oracle's three-pass composition of reference src/panorama.cpp:156-229
+(32FC4 copy -> warpPerspective -> feather + accumulate; normalise).  Bar: the f32 canvas and the u8 panorama
+are bit-exact (same operation order, no FMA)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _scene(synth, n, w, h, rng):
+    imgs, Ms = [], []
+    for i in range(n):
+        img = synth.panorama_tile(w, h, seed=0x3D52 + i)
+        img = np.roll(img, 17 * i, axis=1).copy()
+        a = rng.uniform(-0.06, 0.06)
+        M = np.array([[np.cos(a), -np.sin(a), 20 + i * (w * 0.55)],
+                      [np.sin(a), np.cos(a), 15 + rng.uniform(-8, 8)],
+                      [rng.uniform(-4e-5, 4e-5), rng.uniform(-4e-5, 4e-5), 1]], np.float32)
+        imgs.append(img); Ms.append(M)
+    return imgs, Ms
+
+
+@pytest.mark.parametrize("w,h,n,fw", [(160, 120, 3, 20), (200, 150, 2, 150), (97, 61, 4, 7)])
+def test_paste_and_normalize_bit_exact(dr3, O, ctx, synth, w, h, n, fw):
+    rng = np.random.default_rng(w + n)
+    imgs, Ms = _scene(synth, n, w, h, rng)
+    cw, ch = int(40 + w * (1 + 0.55 * (n - 1)) + 30), h + 50
+    want = np.zeros((ch, cw, 4), np.float32)
+    for img, M in zip(imgs, Ms):
+        O.panorama_add(img, want, M, fw)
+    got_canvas, got_pan = ctx.paste_images(imgs, Ms, (cw, ch), fw)
+    assert np.array_equal(_bits(got_canvas), _bits(want))
+    assert np.array_equal(got_pan, O.normalize_canvas(want))
+    assert got_canvas[..., 3].max() >= 1.0
+    assert got_pan.any()
+
+
+def test_paste_clips_boxes_that_leave_the_canvas(dr3, O, ctx, synth):
+    """bounding boxes partly left of / right of the canvas: the reference indexes unchecked; the oracle and the
+    kernel both skip those columns"""
+    img = synth.panorama_tile(120, 90)
+    for tx in (-40.5, 130.25):
+        M = np.array([[1, 0, tx], [0, 1, 6.5], [1e-5, 0, 1]], np.float32)
+        want = np.zeros((110, 200, 4), np.float32)
+        O.panorama_add(img, want, M, 16)
+        got, _ = ctx.paste_images([img], [M], (200, 110), 16)
+        assert np.array_equal(_bits(got), _bits(want)), tx
+
+
+def test_zero_pixels_carry_no_weight(dr3, O, ctx):
+    """:205-207: a source pixel that is exactly black contributes neither colour nor alpha"""
+    img = np.full((40, 60, 3), 90, np.uint8)
+    img[10:20, 20:40] = 0
+    M = np.array([[1, 0, 8], [0, 1, 4], [0, 0, 1]], np.float32)
+    want = np.zeros((50, 80, 4), np.float32)
+    O.panorama_add(img, want, M, 5)
+    got, pan = ctx.paste_images([img], [M], (80, 50), 5)
+    assert np.array_equal(_bits(got), _bits(want))
+    assert got[16, 35, 3] == 0.0 and got[6, 35, 3] == 1.0 and pan[16, 35].tolist() == [0, 0, 0]
+
+
+def test_normalize_truncation_order(dr3, O, ctx):
+    """(int)canvas / alpha: the int cast comes before the divide"""
+    rng = np.random.default_rng(9)
+    canvas = (rng.random((33, 70, 4), dtype=np.float32) * np.float32(600)).astype(np.float32)
+    canvas[..., 3] = rng.random((33, 70), dtype=np.float32) * 3
+    canvas[5, :, 3] = 0.0
+    canvas[6, :, 3] = -1.0
+    d_c = ctx.to_device(canvas); d_o = ctx.alloc(33 * 70 * 3)
+    ctx.panorama_normalize(d_c, 70, 33, 70 * 16, d_o, 70 * 3)
+    got = d_o.download((33, 70, 3), np.uint8)
+    d_c.free(); d_o.free()
+    assert np.array_equal(got, O.normalize_canvas(canvas))
+    assert not got[5].any() and not got[6].any()

@@ -65,6 +65,7 @@ def test_harness_matches_oracle(dr3, O, synth, tmp_path):
         status = np.fromfile(f, np.uint8, len(pts))
         err = np.fromfile(f, np.float32, len(pts))
         pano = np.fromfile(f, np.uint8, W * H * 3).reshape(H, W, 3)
+        pano_fused = np.fromfile(f, np.uint8, W * H * 3).reshape(H, W, 3)
         levels = []
         for _ in range(2):
             cw, ch = np.fromfile(f, np.int32, 2)
@@ -90,6 +91,11 @@ def test_harness_matches_oracle(dr3, O, synth, tmp_path):
     want = O.normalize_canvas(canvas)
     assert np.array_equal(pano, want)
     assert pano.any()
+    # (2b) the fused device path (dr3hip::WeightedCanvas) against the oracle's own add_img_to_canvas
+    canvas2 = np.zeros((H, W, 4), np.float32)
+    O.panorama_add(tile, canvas2, M, feather)
+    assert np.array_equal(pano_fused, O.normalize_canvas(canvas2))
+    assert O.panorama_bbox(M, tw, th)[0::2] == (min_x, max_x) and np.array_equal(pano_fused, pano)
 
     # (3) Frame-constructor pyramid, byte-for-byte what the reference computes on x86-64
     ref_pyr = O.halfsample_pyramid(A, 3, O.HALF_REF_X86)
