@@ -31,6 +31,7 @@ HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
 PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM = 0, 1, 2, 3, 4, 5, 6, 7
 COMM_ID_BYTES = 128
+WARP_SPHERICAL, WARP_CYLINDRICAL = 1, 2
 
 
 class Dr3HipError(RuntimeError):
@@ -105,6 +106,8 @@ def _signatures():
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
+        "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
+        "dr3hip_warp_local_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
         "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
@@ -237,6 +240,22 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def warp_spherical(self, img, f):
+        """utils::warp_spherical (src/utils.cpp:196-201): map generation fused with the remap"""
+        return self._warp_local(img, WARP_SPHERICAL, f)
+
+    def warp_cylindrical(self, img, f):
+        """utils::warp_cylindrical (src/utils.cpp:267-272)"""
+        return self._warp_local(img, WARP_CYLINDRICAL, f)
+
+    def _warp_local(self, img, kind, f):
+        img = np.ascontiguousarray(img)
+        t = _img_type(img)
+        dst = np.zeros_like(img)
+        self._chk(lib().dr3hip_warp_local(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], t,
+                                          _p(dst), dst.strides[0], int(kind), C.c_float(f)))
+        return dst
 
     # ---- panorama paste (reference src/panorama.cpp:156-229) -----------------------------------
     def panorama_add(self, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, feathering_width):

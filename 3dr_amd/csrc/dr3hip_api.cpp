@@ -908,9 +908,72 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx, const void* d_src, int sw, int sh
     a.src = (const uint8_t*)d_src; a.sw = sw; a.sh = sh; a.sstride = sstride;
     a.dst = (uint8_t*)d_dst; a.dw = dw; a.dh = dh; a.dstride = dstride;
     a.mapx = d_mapx; a.mapy = d_mapy; a.map_stride = map_stride;
+    a.mode = 0; a.tx0 = a.tx1 = a.ty0 = a.ty1 = nullptr; a.f = a.half_w = a.half_h = 0.f;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_REMAP, pe);
     HIPCHK(ctx, launch_remap(a, type, ctx->stream));
     prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+// utils::warp_spherical / warp_cylindrical: tables on the host, everything per-pixel in remap_kernel<TYPE, kind>
+int dr3hip_warp_local_dev(dr3hip_ctx* ctx, const void* d_src, int w, int h, int sstride, int type,
+                          void* d_dst, int dstride, int kind, float f)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    const int esz = type_elem_bytes(type);
+    if (!d_src || !d_dst || esz == 0 || w < 1 || h < 1 || sstride < w * esz || dstride < w * esz ||
+        (kind != DR3HIP_WARP_SPHERICAL && kind != DR3HIP_WARP_CYLINDRICAL))
+        return fail(ctx, DR3HIP_EINVAL, "warp_local: bad arguments");
+    if (esz >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst | (uintptr_t)sstride | (uintptr_t)dstride) & (uintptr_t)(esz - 1)))
+        return fail(ctx, DR3HIP_EINVAL, "warp_local: pointers/strides must be %d-byte aligned", esz);
+    // per-column / per-row tables, reference src/utils.cpp:151-176 (spherical), :229-254 (cylindrical):
+    //   xf = (float)((j - 0.5 w) / f) with the subtraction and the division in double (0.5 * w is a double), then
+    //   the unqualified sin / cos of that TU on the float, i.e. ::sin(double)
+    std::vector<double> tab((size_t)2 * w + (size_t)2 * h);
+    double* tx0 = tab.data(); double* tx1 = tx0 + w; double* ty0 = tx1 + w; double* ty1 = ty0 + h;
+    for (int j = 0; j < w; ++j) {
+        const float xf = (float)(((double)(float)j - 0.5 * w) / (double)f);
+        if (kind == DR3HIP_WARP_SPHERICAL) { tx0[j] = std::sin((double)xf); tx1[j] = std::cos((double)xf); }
+        else { tx0[j] = (double)(float)std::sin((double)xf); tx1[j] = (double)(float)std::cos((double)xf); }
+    }
+    for (int i = 0; i < h; ++i) {
+        const float yf = (float)(((double)(float)i - 0.5 * h) / (double)f);
+        if (kind == DR3HIP_WARP_SPHERICAL) { ty0[i] = std::sin((double)yf); ty1[i] = std::cos((double)yf); }
+        else { ty0[i] = (double)yf; ty1[i] = 0.0; }
+    }
+    DeviceGuard g(ctx->device);
+    int rc;
+    if ((rc = stage_reserve(ctx, 6, tab.size() * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[6].p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                       // tab is a local
+    RemapArgs a;
+    a.src = (const uint8_t*)d_src; a.sw = w; a.sh = h; a.sstride = sstride;
+    a.dst = (uint8_t*)d_dst; a.dw = w; a.dh = h; a.dstride = dstride;
+    a.mapx = a.mapy = nullptr; a.map_stride = 0;
+    a.mode = kind;
+    a.tx0 = (const double*)ctx->stage[6].p; a.tx1 = a.tx0 + w; a.ty0 = a.tx1 + w; a.ty1 = a.ty0 + h;
+    a.f = f; a.half_w = (float)(0.5 * w); a.half_h = (float)(0.5 * h);    // u = 0.5 * w + xhat * f as a float MatExpr (:186-187)
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_REMAP, pe);
+    HIPCHK(ctx, launch_remap(a, type, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_warp_local(dr3hip_ctx* ctx, const void* src, int w, int h, int sstride, int type,
+                      void* dst, int dstride, int kind, float f)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    const int esz = type_elem_bytes(type);
+    if (!src || !dst || esz == 0 || w < 1 || h < 1 || sstride < w * esz || dstride < w * esz)
+        return fail(ctx, DR3HIP_EINVAL, "warp_local: bad arguments");
+    DeviceGuard g(ctx->device);
+    const int sp = align_up(w * esz, 64);
+    int rc;
+    if ((rc = stage_reserve(ctx, 0, (size_t)sp * h)) || (rc = stage_reserve(ctx, 1, (size_t)sp * h))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0].p, sp, src, sstride, (size_t)w * esz, h, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = dr3hip_warp_local_dev(ctx, ctx->stage[0].p, w, h, sp, type, ctx->stage[1].p, sp, kind, f))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(dst, dstride, ctx->stage[1].p, sp, (size_t)w * esz, h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return DR3HIP_OK;
 }
 

@@ -79,7 +79,11 @@ struct PanoNormArgs {      // Panorama::normalize_canvas (src/panorama.cpp:215-2
 struct RemapArgs {
     const uint8_t* src; int sw, sh, sstride;
     uint8_t* dst;       int dw, dh, dstride;
-    const float* mapx; const float* mapy; int map_stride;   // bytes
+    const float* mapx; const float* mapy; int map_stride;   // bytes (mode 0)
+    int mode;                                               // 0 maps from memory, 1 spherical, 2 cylindrical (generated)
+    const double* tx0; const double* tx1;                   // per-column tables (dw entries each), see remap_kernel
+    const double* ty0; const double* ty1;                   // per-row tables (dh entries each)
+    float f, half_w, half_h;
 };
 
 struct HalfArgs {

