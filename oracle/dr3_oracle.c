@@ -506,6 +506,111 @@ float dr3o_shi_tomasi_score(const uint8_t* img, int w, int h, int stride, int u,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* FAST-10 + 3x3 non-max + grid-best Shi-Tomasi (src/features.cpp:43-98)                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Rosten's ring order (make_offsets): (0,3) (1,3) (2,2) (3,1) (3,0) (3,-1) (2,-2) (1,-3) (0,-3) ... */
+static const int k_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int k_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+/* the corner test of fast_corner_detect_10 at threshold b: 10 contiguous ring pixels > c + b or < c - b */
+static int fast10_is_corner(const uint8_t* p, int stride, int b)
+{
+    const int c = p[0], cb = c + b, c_b = c - b;
+    int start, k;
+    for (start = 0; start < 16; ++start) {
+        int brighter = 1, darker = 1;
+        for (k = 0; k < 10 && (brighter || darker); ++k) {
+            const int i = (start + k) & 15;
+            const int v = p[k_ring_dy[i] * stride + k_ring_dx[i]];
+            if (!(v > cb)) brighter = 0;
+            if (!(v < c_b)) darker = 0;
+        }
+        if (brighter || darker) return 1;
+    }
+    return 0;
+}
+
+/* fast_corner_score_10: the library's bisection */
+static int fast10_score(const uint8_t* p, int stride, int bstart)
+{
+    int bmin = bstart, bmax = 255, b = (bmax + bmin) / 2;
+    for (;;) {
+        if (fast10_is_corner(p, stride, b)) bmin = b; else bmax = b;
+        if (bmin == bmax - 1 || bmin == bmax) return bmin;
+        b = (bmin + bmax) / 2;
+    }
+}
+
+int dr3o_fast10_score_map(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score_map)
+{
+    int x, y, n = 0;
+    memset(score_map, 0, (size_t)w * h);
+    for (y = 3; y < h - 3; ++y)                     /* fast_corner_detect_10 scans [3, size - 3) */
+        for (x = 3; x < w - 3; ++x) {
+            const uint8_t* p = img + (size_t)y * stride + x;
+            if (fast10_is_corner(p, stride, threshold)) {
+                score_map[(size_t)y * w + x] = (uint8_t)fast10_score(p, stride, threshold);
+                ++n;
+            }
+        }
+    return n;
+}
+
+int dr3o_fast_nonmax_3x3(const uint8_t* score_map, int w, int h, uint8_t* keep)
+{
+    int x, y, dx, dy, n = 0;
+    memset(keep, 0, (size_t)w * h);
+    for (y = 0; y < h; ++y)
+        for (x = 0; x < w; ++x) {
+            const int s = score_map[(size_t)y * w + x];
+            int ok = s > 0;
+            for (dy = -1; dy <= 1 && ok; ++dy)
+                for (dx = -1; dx <= 1 && ok; ++dx) {
+                    const int xx = x + dx, yy = y + dy;
+                    if ((dx || dy) && xx >= 0 && xx < w && yy >= 0 && yy < h) {
+                        const int t = score_map[(size_t)yy * w + xx];
+                        if (t > 0 && t >= s) ok = 0;      /* Compare(X, Y) ((X) >= (Y)) on adjacent corners */
+                    }
+                }
+            if (ok) { keep[(size_t)y * w + x] = 1; ++n; }
+        }
+    return n;
+}
+
+int dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int w, int h, int n_levels,
+                          int cell_size, int fast_threshold, double detection_threshold, const uint8_t* occupancy,
+                          int* cell_x, int* cell_y, float* cell_score, int* cell_level)
+{
+    const int grid_cols = (int)ceil((double)w / cell_size), grid_rows = (int)ceil((double)h / cell_size);
+    const int n_cells = grid_cols * grid_rows;
+    int lvl, k, x, y, n = 0;
+    for (k = 0; k < n_cells; ++k) { cell_x[k] = 0; cell_y[k] = 0; cell_score[k] = (float)detection_threshold; cell_level[k] = 0; }
+    for (lvl = 0; lvl < n_levels; ++lvl) {
+        const int lw = w >> lvl, lh = h >> lvl, scale = 1 << lvl;
+        uint8_t* sm = (uint8_t*)malloc((size_t)lw * lh);
+        uint8_t* keep = (uint8_t*)malloc((size_t)lw * lh);
+        if (!sm || !keep) { free(sm); free(keep); return -1; }
+        dr3o_fast10_score_map(levels[lvl], lw, lh, strides[lvl], fast_threshold, sm);
+        dr3o_fast_nonmax_3x3(sm, lw, lh, keep);
+        for (y = 0; y < lh; ++y)                    /* corners come out of the detector in raster order */
+            for (x = 0; x < lw; ++x) {
+                float score;
+                if (!keep[(size_t)y * lw + x]) continue;
+                k = ((y * scale) / cell_size) * grid_cols + (x * scale) / cell_size;
+                if (occupancy && occupancy[k]) continue;
+                score = dr3o_shi_tomasi_score(levels[lvl], lw, lh, strides[lvl], x, y);
+                if (score > cell_score[k]) { cell_x[k] = x * scale; cell_y[k] = y * scale; cell_score[k] = score; cell_level[k] = lvl; }
+            }
+        free(sm); free(keep);
+    }
+    for (k = 0; k < n_cells; ++k) {
+        if ((double)cell_score[k] > detection_threshold) ++n; else cell_level[k] = -1;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* A-4 / A-5  warpPerspective, remap                                                          */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -110,6 +110,24 @@ int  dr3o_remap_bilinear(const void* src, int sw, int sh, int sstride, int type,
 /* src/utils.cpp:282-321 */
 float dr3o_shi_tomasi_score(const uint8_t* img, int w, int h, int stride, int u, int v);
 
+/* FAST-10 as the reference calls it (src/features.cpp:53-74): fast::fast_corner_detect_10(img, w, h, stride, 20),
+ * fast::fast_corner_score_10(.., 20, scores), fast::fast_nonmax_3x3.  The `fast` library (uzh-rpg/fast, Rosten's
+ * generated detector) is an un-vendored dependency (CMakeLists.txt:17): restated from the published algorithm --
+ * 16-pixel Bresenham ring of radius 3, corner = 10 contiguous ring pixels all > p + b or all < p - b, score =
+ * largest b found by the library's bisection over [b, 255), 3x3 non-maximum suppression that drops a corner when
+ * an adjacent corner's score is >= its own.  PARITY UNPINNED (the tie rule of the suppression in particular).
+ * score_map: w*h u8, 0 = no corner else the score (>= threshold >= 1).  Returns the corner count. */
+int  dr3o_fast10_score_map(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score_map);
+/* keep[i] = 1 for corners surviving fast_nonmax_3x3; returns how many */
+int  dr3o_fast_nonmax_3x3(const uint8_t* score_map, int w, int h, uint8_t* keep);
+/* feature_detection::FastDetector::detect (src/features.cpp:43-98) over a half-sample pyramid:
+ * per grid cell the FAST corner with the best Shi-Tomasi score over all levels.  levels[l] points to level l
+ * (w>>l x h>>l, stride[l]); occupancy (may be NULL) has grid_cols*grid_rows bytes.  Output arrays have one
+ * entry per cell; cell_level[k] = -1 where no corner beat detection_threshold.  Returns the feature count. */
+int  dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int w, int h, int n_levels,
+                           int cell_size, int fast_threshold, double detection_threshold, const uint8_t* occupancy,
+                           int* cell_x, int* cell_y, float* cell_score, int* cell_level);
+
 /* src/utils.cpp:125-187 / :203-265 -- spherical / cylindrical map generation (u,v f32 planes w*h) */
 void dr3o_spherical_map(int w, int h, float f, float* u, float* v);
 void dr3o_cylindrical_map(int w, int h, float f, float* u, float* v);

@@ -73,6 +73,12 @@ def lib():
         L.dr3o_normalize_canvas.restype = None
         L.dr3o_linspace_f32.argtypes = [C.c_float, C.c_float, ip, vp]
         L.dr3o_linspace_f32.restype = None
+        L.dr3o_fast10_score_map.argtypes = [vp, ip, ip, ip, ip, vp]
+        L.dr3o_fast10_score_map.restype = ip
+        L.dr3o_fast_nonmax_3x3.argtypes = [vp, ip, ip, vp]
+        L.dr3o_fast_nonmax_3x3.restype = ip
+        L.dr3o_fast_detect_grid.argtypes = [vp, vp, ip, ip, ip, ip, ip, C.c_double, vp, vp, vp, vp, vp]
+        L.dr3o_fast_detect_grid.restype = ip
         L.dr3o_panorama_bbox.argtypes = [vp, ip, ip, vp, vp, vp, vp]
         L.dr3o_panorama_bbox.restype = None
         L.dr3o_feather_ramp.argtypes = [ip, ip, ip, vp]
@@ -285,3 +291,37 @@ def panorama_add(img, canvas, M, feathering_width, n_threads=0):
     if r != 0:
         raise ValueError("panorama_add failed (%d)" % r)
     return canvas
+
+
+def fast10_score_map(img, threshold=20):
+    """FAST-10 corner scores (0 = no corner) as fast_corner_detect_10 + fast_corner_score_10 give them"""
+    img = _gray(img)
+    h, w = img.shape
+    sm = np.zeros((h, w), np.uint8)
+    lib().dr3o_fast10_score_map(_p(img), w, h, img.strides[0], int(threshold), _p(sm))
+    return sm
+
+
+def fast_nonmax_3x3(score_map):
+    sm = np.ascontiguousarray(score_map, np.uint8)
+    keep = np.zeros_like(sm)
+    lib().dr3o_fast_nonmax_3x3(_p(sm), sm.shape[1], sm.shape[0], _p(keep))
+    return keep
+
+
+def fast_detect_grid(pyr, cell_size=30, fast_threshold=20, detection_threshold=20.0, occupancy=None):
+    """FastDetector::detect (src/features.cpp:43-98) -> (x, y, score, level) arrays per grid cell; level -1 = empty"""
+    pyr = [_gray(p) for p in pyr]
+    h, w = pyr[0].shape
+    n = len(pyr)
+    gc, gr = -(-w // cell_size), -(-h // cell_size)
+    ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pyr])
+    strides = (C.c_int * n)(*[p.strides[0] for p in pyr])
+    cx, cy, cl = (np.zeros(gc * gr, np.int32) for _ in range(3))
+    cs = np.zeros(gc * gr, np.float32)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+    r = lib().dr3o_fast_detect_grid(ptrs, strides, w, h, n, int(cell_size), int(fast_threshold), float(detection_threshold),
+                                    None if occ is None else _p(occ), _p(cx), _p(cy), _p(cs), _p(cl))
+    if r < 0:
+        raise MemoryError("dr3o_fast_detect_grid")
+    return cx, cy, cs, cl
