@@ -50,6 +50,10 @@ class LevelInfo(C.Structure):
                 ("der_pitch", C.c_int), ("der_slot_step", C.c_size_t), ("der", C.c_void_p)]
 
 
+class Corner(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("level", C.c_int), ("score", C.c_float)]
+
+
 class WarpJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("sw", C.c_int), ("sh", C.c_int), ("sstride", C.c_int),
                 ("dst", C.c_void_p), ("dw", C.c_int), ("dh", C.c_int), ("dstride", C.c_int),
@@ -106,6 +110,9 @@ def _signatures():
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
+        "dr3hip_fast_grid_size": ([ip, ip, ip, P(ip), P(ip)], ip),
+        "dr3hip_fast_detect": ([vp, vp, ip, ip, ip, ip, ip, ip, C.c_double, vp, ip, P(Corner)], ip),
+        "dr3hip_fast_score_map": ([vp, vp, ip, ip, ip, ip, vp], ip),
         "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_warp_local_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
@@ -240,6 +247,28 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def fast_score_map(self, img, threshold=20):
+        """FAST-10 corner scores of one gray image (0 = no corner)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        sm = np.zeros(img.shape, np.uint8)
+        self._chk(lib().dr3hip_fast_score_map(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], int(threshold), _p(sm)))
+        return sm
+
+    def fast_detect(self, img, n_levels=3, cell_size=30, fast_threshold=20, detection_threshold=20.0, occupancy=None,
+                    mode=HALF_REF_X86):
+        """FastDetector::detect (src/features.cpp:43-98) -> (x, y, score, level) arrays per grid cell; level -1 = empty"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        gc, gr = C.c_int(), C.c_int()
+        lib().dr3hip_fast_grid_size(w, h, int(cell_size), C.byref(gc), C.byref(gr))
+        n = gc.value * gr.value
+        cells = (Corner * n)()
+        occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+        self._chk(lib().dr3hip_fast_detect(self.h, _p(img), w, h, img.strides[0], int(n_levels), int(cell_size), int(fast_threshold),
+                                           float(detection_threshold), None if occ is None else _p(occ), int(mode), cells))
+        a = np.frombuffer(cells, dtype=np.dtype([("x", np.int32), ("y", np.int32), ("level", np.int32), ("score", np.float32)]))
+        return a["x"].copy(), a["y"].copy(), a["score"].copy(), a["level"].copy()
 
     def warp_spherical(self, img, f):
         """utils::warp_spherical (src/utils.cpp:196-201): map generation fused with the remap"""

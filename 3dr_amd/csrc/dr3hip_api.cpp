@@ -223,6 +223,109 @@ int dr3hip_memset(dr3hip_ctx* ctx, void* dst, int value, size_t bytes)
     return DR3HIP_OK;
 }
 
+// ---- FAST-10 + grid-best Shi-Tomasi -----------------------------------------------------------
+int dr3hip_fast_grid_size(int w, int h, int cell_size, int* grid_cols, int* grid_rows)
+{
+    if (w < 1 || h < 1 || cell_size < 1 || !grid_cols || !grid_rows) return DR3HIP_EINVAL;
+    *grid_cols = (int)std::ceil((double)w / cell_size);               // src/features.cpp:14-15
+    *grid_rows = (int)std::ceil((double)h / cell_size);
+    return DR3HIP_OK;
+}
+
+int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int fast_threshold, uint8_t* score_map)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!img || !score_map || w < 1 || h < 1 || stride < w || fast_threshold < 1 || fast_threshold > 254)
+        return fail(ctx, DR3HIP_EINVAL, "fast_score_map: bad arguments");
+    DeviceGuard g(ctx->device);
+    const int ip = align_up(w, 64);
+    int rc;
+    if ((rc = stage_reserve(ctx, 4, (size_t)ip * h + 256)) || (rc = stage_reserve(ctx, 1, (size_t)ip * h + 256))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[4].p, ip, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    FastArgs a;
+    a.img = (const uint8_t*)ctx->stage[4].p; a.w = w; a.h = h; a.stride = ip;
+    a.score = (uint8_t*)ctx->stage[1].p; a.spitch = ip; a.threshold = fast_threshold;
+    a.level = 0; a.cell_size = 1; a.grid_cols = 1; a.det_threshold = 0.f; a.occupancy = nullptr; a.cells = nullptr;
+    HIPCHK(ctx, launch_fast_score(a, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(score_map, w, a.score, ip, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int n_levels,
+                       int cell_size, int fast_threshold, double detection_threshold,
+                       const uint8_t* occupancy, int halfsample_mode, dr3hip_corner* cells)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!img || !cells || w < 8 || h < 8 || stride < w || n_levels < 1 || n_levels > 8 || cell_size < 1 ||
+        fast_threshold < 1 || fast_threshold > 254 || w >= 16384 || h >= 16384 || (w >> (n_levels - 1)) < 1 || (h >> (n_levels - 1)) < 1)
+        return fail(ctx, DR3HIP_EINVAL, "fast_detect: bad arguments");
+    int gc, gr;
+    dr3hip_fast_grid_size(w, h, cell_size, &gc, &gr);
+    const int n_cells = gc * gr;
+    DeviceGuard g(ctx->device);
+    // device layout in stage[4]: the half-sample pyramid exactly as dr3hip_halfsample_pyramid lays it out
+    // (level 0 keeps the caller's stride, deeper levels are continuous like the reference's cv::Mat levels)
+    int rc;
+    std::vector<int> lw(n_levels), lh(n_levels), lp(n_levels);
+    std::vector<size_t> off(n_levels);
+    size_t total = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        lw[l] = l ? lw[l - 1] / 2 : w; lh[l] = l ? lh[l - 1] / 2 : h;
+        lp[l] = l ? lw[l] : stride;
+        off[l] = total;
+        total += (size_t)align_up(lp[l] * lh[l] + 64, 256);
+    }
+    const int sp = align_up(w, 64);
+    const size_t cells_off = (size_t)align_up(n_cells, 256);          // stage[6]: occupancy bytes, then the cell keys
+    if ((rc = stage_reserve(ctx, 4, total)) || (rc = stage_reserve(ctx, 1, (size_t)sp * h + 256)) ||
+        (rc = stage_reserve(ctx, 6, cells_off + sizeof(unsigned long long) * (size_t)n_cells))) return rc;
+    uint8_t* base = (uint8_t*)ctx->stage[4].p;
+    uint8_t* d_occ = (uint8_t*)ctx->stage[6].p;
+    unsigned long long* d_cells = (unsigned long long*)(d_occ + cells_off);
+    // every cell starts as Corner(0, 0, detection_threshold, 0) (src/features.cpp:49): score bits of the
+    // threshold with the lowest tie rank, so only a strictly greater score replaces it
+    const float thr_f = (float)detection_threshold;
+    if (!(thr_f >= 0.f)) return fail(ctx, DR3HIP_EINVAL, "fast_detect: detection_threshold must be >= 0");
+    uint32_t thr_bits; memcpy(&thr_bits, &thr_f, 4);
+    std::vector<unsigned long long> init((size_t)n_cells, ((unsigned long long)thr_bits << 32) | 0xffffffffull);
+    HIPCHK(ctx, hipMemcpyAsync(d_cells, init.data(), sizeof(unsigned long long) * (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
+    if (occupancy) HIPCHK(ctx, hipMemcpyAsync(d_occ, occupancy, (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + off[0], img, (size_t)stride * (h - 1) + w, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                   // init is a local
+    for (int l = 1; l < n_levels; ++l)
+        if ((rc = dr3hip_halfsample_dev(ctx, base + off[l - 1], lw[l - 1], lh[l - 1], lp[l - 1], base + off[l], lp[l], halfsample_mode))) return rc;
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_FAST, pe);
+    for (int l = 0; l < n_levels; ++l) {
+        FastArgs a;
+        a.img = base + off[l]; a.w = lw[l]; a.h = lh[l]; a.stride = lp[l];
+        a.score = (uint8_t*)ctx->stage[1].p; a.spitch = sp; a.threshold = fast_threshold;
+        a.level = l; a.cell_size = cell_size; a.grid_cols = gc; a.det_threshold = thr_f;
+        a.occupancy = occupancy ? d_occ : nullptr; a.cells = d_cells;
+        HIPCHK(ctx, launch_fast_score(a, ctx->stream));
+        HIPCHK(ctx, launch_fast_select(a, ctx->stream));
+    }
+    prof_end(ctx, pe);
+    std::vector<unsigned long long> keys((size_t)n_cells);
+    HIPCHK(ctx, hipMemcpyAsync(keys.data(), d_cells, sizeof(unsigned long long) * (size_t)n_cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int n_feat = 0;
+    for (int k = 0; k < n_cells; ++k) {
+        dr3hip_corner& c = cells[k];
+        const uint32_t bits = (uint32_t)(keys[k] >> 32), order = ~(uint32_t)keys[k];
+        memcpy(&c.score, &bits, 4);
+        if (keys[k] == init[0] || !((double)c.score > detection_threshold)) {         // :88 corner.score > detection_threshold
+            c.x = 0; c.y = 0; c.level = -1; c.score = thr_f;
+            continue;
+        }
+        c.level = (int)(order >> 28);
+        c.x = (int)(order & 0x3fffu) << c.level;                                       // Corner(xy.x * scale, xy.y * scale, ..)
+        c.y = (int)((order >> 14) & 0x3fffu) << c.level;
+        ++n_feat;
+    }
+    return n_feat;
+}
+
 // ---- panorama paste -------------------------------------------------------------------------
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags);      // defined with the warp entry points below

@@ -76,6 +76,16 @@ struct PanoNormArgs {      // Panorama::normalize_canvas (src/panorama.cpp:215-2
     uint8_t* out;        int ostride;
 };
 
+struct FastArgs {          // FAST-10 score map + grid-best selection of one pyramid level (fast_kernels.hip)
+    const uint8_t* img; int w, h, stride;         // level image
+    uint8_t* score;     int spitch;               // u8 score map (0 = no corner)
+    int threshold;                                // FAST threshold (reference: 20)
+    int level, cell_size, grid_cols;
+    float det_threshold;                          // (float)detection_threshold: the initial Corner score of every cell
+    const uint8_t* occupancy;                     // device, grid cells, may be null
+    unsigned long long* cells;                    // device, per cell: (score bits << 32) | ~raster order
+};
+
 struct RemapArgs {
     const uint8_t* src; int sw, sh, sstride;
     uint8_t* dst;       int dw, dh, dstride;
@@ -98,6 +108,8 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
+hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
+hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 

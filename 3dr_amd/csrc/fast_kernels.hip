@@ -1,0 +1,129 @@
+// fast_kernels.hip -- FAST-10 corner scores, 3x3 non-maximum suppression and the grid-best Shi-Tomasi
+// selection of feature_detection::FastDetector::detect (reference src/features.cpp:43-98,
+// utils::shi_tomasi_score src/utils.cpp:282-321) for gfx950.  SURVEY 8f.2: this is what produces the
+// points the LK tracker consumes.  The `fast` library the reference links (CMakeLists.txt:17) is not
+// vendored; its published algorithm is restated here ("FAST"), parity unpinned.
+//   fast10_score_kernel : one lane per pixel.  The library finds the score by bisection over the corner
+//                         test; the fixed point of that search has a closed form -- the largest b for which
+//                         10 contiguous ring pixels are all > p + b (or all < p - b) is
+//                         max over the 16 arcs of min over the arc of (ring - p) (resp. p - ring), minus 1 --
+//                         evaluated with a doubling sliding minimum (windows 2, 4, 8, 10).  A pixel is a
+//                         corner at threshold t iff that score is >= t.
+//   fast_select_kernel  : one lane per pixel of the score map: 3x3 non-max (a corner falls when an adjacent
+//                         corner scores >= it), occupancy test, Shi-Tomasi score of the 8x8 box (integer
+//                         sums are exact in the reference's f32 accumulators: 64 * 255^2 < 2^24), then a
+//                         64-bit atomicMax per grid cell on (score bits, ~raster order): the reference keeps
+//                         the first corner of the best score in level-major raster order.
+#include "dr3hip_internal.h"
+
+namespace dr3 {
+namespace {
+
+// ring order of Rosten's make_offsets: (0,3) (1,3) (2,2) (3,1) (3,0) (3,-1) (2,-2) (1,-3) (0,-3) (-1,-3) ... (-1,3)
+__device__ __forceinline__ int max_arc10(const int v[16])
+{
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2[i] = min(v[i], v[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m8[i] = min(m4[i], m4[(i + 4) & 15]);
+    int best = -1000;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], m2[(i + 8) & 15]));      // window of 10 starting at i
+    return best;
+}
+
+__global__ __launch_bounds__(256) void fast10_score_kernel(const FastArgs a)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.w || y >= a.h) return;
+    uint8_t out = 0;
+    if (x >= 3 && y >= 3 && x < a.w - 3 && y < a.h - 3) {             // fast_corner_detect_10 scans [3, size - 3)
+        const uint8_t* p = a.img + (long long)y * a.stride + x;
+        const int c = p[0];
+        int d[16], e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int dy = (i < 2 || i == 15) ? 3 : (i == 2 || i == 14) ? 2 : (i == 3 || i == 13) ? 1 : (i == 4 || i == 12) ? 0
+                         : (i == 5 || i == 11) ? -1 : (i == 6 || i == 10) ? -2 : -3;
+            const int dx = (i == 0 || i == 8) ? 0 : (i == 1 || i == 7) ? 1 : (i == 2 || i == 6) ? 2 : (i >= 3 && i <= 5) ? 3
+                         : (i == 9 || i == 15) ? -1 : (i == 10 || i == 14) ? -2 : -3;
+            d[i] = (int)p[dy * a.stride + dx] - c;
+            e[i] = -d[i];
+        }
+        const int score = max(max_arc10(d), max_arc10(e)) - 1;
+        if (score >= a.threshold) out = (uint8_t)score;               // <= 254
+    }
+    a.score[(long long)y * a.spitch + x] = out;
+}
+
+// utils::shi_tomasi_score, reference src/utils.cpp:282-321
+__device__ float shi_tomasi(const uint8_t* __restrict__ img, int w, int h, int stride, int u, int v)
+{
+    const int x_min = u - 4, x_max = u + 4, y_min = v - 4, y_max = v + 4;
+    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.f;
+    int sxx = 0, syy = 0, sxy = 0;                                    // exact: each fits 23 bits
+    for (int y = y_min; y < y_max; ++y) {
+        const uint8_t* r = img + (long long)y * stride + x_min;
+        for (int x = 0; x < 8; ++x) {
+            const int dx = (int)r[x + 1] - (int)r[x - 1];
+            const int dy = (int)r[x + stride] - (int)r[x - stride];
+            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+        }
+    }
+    const float dXX = (float)((double)(float)sxx / 128.0), dYY = (float)((double)(float)syy / 128.0), dXY = (float)((double)(float)sxy / 128.0);
+    const float t = dXX + dYY;
+    const float disc = t * t - 4.f * (dXX * dYY - dXY * dXY);
+    return (float)(0.5 * ((double)t - sqrt((double)disc)));
+}
+
+__global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.w || y >= a.h) return;
+    const uint8_t* sp = a.score + (long long)y * a.spitch + x;
+    const int s = sp[0];
+    if (s == 0) return;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if ((dx | dy) == 0) continue;
+            const int xx = x + dx, yy = y + dy;
+            if (xx < 0 || xx >= a.w || yy < 0 || yy >= a.h) continue;
+            const int t = sp[dy * a.spitch + dx];
+            if (t > 0 && t >= s) return;                              // fast_nonmax_3x3
+        }
+    const int scale = 1 << a.level;
+    const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
+    if (a.occupancy && a.occupancy[k]) return;
+    const float score = shi_tomasi(a.img, a.w, a.h, a.stride, x, y);
+    if (!(score > a.det_threshold)) return;                           // can never beat the cell's initial Corner
+    const uint32_t order = ((uint32_t)a.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)~order;
+    atomicMax(a.cells + k, key);
+}
+
+}  // namespace
+
+hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
+{
+    if (a.w <= 0 || a.h <= 0) return hipSuccess;
+    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, 1);
+    hipLaunchKernelGGL(fast10_score_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast_select(const FastArgs& a, hipStream_t s)
+{
+    if (a.w <= 0 || a.h <= 0) return hipSuccess;
+    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, 1);
+    hipLaunchKernelGGL(fast_select_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dr3

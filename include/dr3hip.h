@@ -189,6 +189,31 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
 int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, int sstride,
                           uint8_t* d_dst, int dstride, int mode);
 
+/* ---- FAST-10 + grid-best Shi-Tomasi detector --------------------------------------------- */
+/* feature_detection::FastDetector::detect (reference src/features.cpp:43-98): on every level of the
+ * frame's half-sample pyramid (utils::create_img_pyramid, src/frame.cpp:13-20) FAST-10 corners at
+ * `fast_threshold` (reference: 20) with their bisection scores, 3x3 non-maximum suppression, and per grid
+ * cell (cell_size, reference Config::cell_size() = 30) the corner with the best utils::shi_tomasi_score
+ * (src/utils.cpp:282-321) above detection_threshold (reference Config::min_harris_corner_score() = 20).
+ * These are the points dr3hip_lk_track receives.  The `fast` library is an un-vendored dependency of the
+ * reference: its published algorithm is restated, parity unpinned. */
+typedef struct dr3hip_corner {
+    int x, y;        /* level-0 pixel coordinates (corner position * 2^level), as Corner::x / ::y */
+    int level;       /* pyramid level the corner was found on; -1: the cell holds no feature */
+    float score;     /* Shi-Tomasi score */
+} dr3hip_corner;
+/* grid geometry of Detector::Detector (src/features.cpp:7-17) */
+int dr3hip_fast_grid_size(int w, int h, int cell_size, int* grid_cols, int* grid_rows);
+/* img: host gray frame; occupancy: host, grid_cols*grid_rows bytes or NULL (Detector::flag_features_grid);
+ * halfsample_mode: DR3HIP_HALF_* used for the pyramid; cells: grid_cols*grid_rows entries out.
+ * Returns the number of features, or < 0. */
+int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int n_levels,
+                       int cell_size, int fast_threshold, double detection_threshold,
+                       const uint8_t* occupancy, int halfsample_mode, dr3hip_corner* cells);
+/* the FAST-10 score map of one image alone (tests, tooling): score_map w*h u8, 0 = no corner */
+int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int fast_threshold,
+                          uint8_t* score_map);
+
 /* ---- spherical / cylindrical pre-warp ------------------------------------------------- */
 /* utils::warp_spherical / warp_cylindrical (reference src/utils.cpp:196-201, :267-272): map generation
  * (compute_spherical_warping :125-187, compute_cylindrical_warping :203-265) fused with warp_local's
@@ -256,7 +281,8 @@ int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on 
 #define DR3HIP_PROF_PYR_L0  5   /* the level-0 fused pyrDown+Scharr kernel alone (dominant HBM kernel) */
 #define DR3HIP_PROF_PANO_ADD  6 /* fused panorama paste kernel                                        */
 #define DR3HIP_PROF_PANO_NORM 7
-#define DR3HIP_PROF_SLOTS   8
+#define DR3HIP_PROF_FAST      8 /* FAST score + select kernels of one dr3hip_fast_detect (all levels)   */
+#define DR3HIP_PROF_SLOTS   9
 int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
 int dr3hip_profile_reset(dr3hip_ctx* ctx);

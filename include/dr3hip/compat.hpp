@@ -6,6 +6,8 @@
 //     cv::warpPerspective        src/stitch.cpp:73-74, src/panorama.cpp:192 -> dr3hip::warpPerspective
 //     cv::remap                  src/utils.cpp:191                -> dr3hip::remap
 //     utils::create_img_pyramid  src/utils.cpp:421-430 (src/frame.cpp:18) -> dr3hip::create_img_pyramid
+//     feature_detection::FastDetector::detect  src/features.cpp:43-98 (src/frame.cpp:57, src/initialization.cpp:552)
+//                                                                 -> dr3hip::FastDetector
 //     utils::warp_spherical / warp_cylindrical  src/utils.cpp:196-201, :267-272 -> dr3hip::warp_spherical / _cylindrical
 //     Panorama::paste_images / add_img_to_canvas / normalize_canvas  src/panorama.cpp:143-229
 //                                                                 -> dr3hip::WeightedCanvas
@@ -211,6 +213,42 @@ inline void create_img_pyramid(const MatView& img_lvl_0, int n_levels, std::vect
     c.check(dr3hip_halfsample_pyramid(c.get(), static_cast<const uint8_t*>(img_lvl_0.data), img_lvl_0.cols, img_lvl_0.rows,
                                       (int)img_lvl_0.step, n_levels, mode, ptrs.data(), strides.data()), "create_img_pyramid");
 }
+
+// feature_detection::FastDetector (include/features.hpp:117-130, src/features.cpp:36-98): same constructor
+// arguments and the same grid bookkeeping (flag_grid / reset_grid); detect() takes the level-0 image (the
+// half-sample pyramid the reference passes as img_pyr is rebuilt on the device) and returns the corners the
+// reference turns into Feature objects (:86-93: one per cell whose score beats detection_threshold).
+struct Corner { int x, y, level; float score; };       // feature_detection::Corner (include/features.hpp:66-76)
+class FastDetector {
+public:
+    FastDetector(int img_w, int img_h, int cell_size, int n_pyr_levels, int device = 0)
+        : w_(img_w), h_(img_h), cell_size_(cell_size), n_pyr_levels_(n_pyr_levels), device_(device) {
+        if (dr3hip_fast_grid_size(img_w, img_h, cell_size, &grid_n_cols_, &grid_n_rows_) != DR3HIP_OK)
+            throw Error(DR3HIP_EINVAL, "FastDetector: bad geometry");
+        grid_occupancy_.assign((std::size_t)grid_n_cols_ * grid_n_rows_, 0);
+    }
+    void reset_grid() { grid_occupancy_.assign(grid_occupancy_.size(), 0); }                   // src/features.cpp:19-21
+    void flag_grid(double px_x, double px_y) {                                                   // :23-27
+        grid_occupancy_.at((std::size_t)(static_cast<int>(px_y / cell_size_) * grid_n_cols_ + static_cast<int>(px_x / cell_size_))) = 1;
+    }
+    void detect(const MatView& img_lvl_0, double detection_threshold, std::vector<Corner>& corners) {
+        if (img_lvl_0.empty() || img_lvl_0.type != DR3HIP_8UC1 || img_lvl_0.cols != w_ || img_lvl_0.rows != h_)
+            throw Error(DR3HIP_EINVAL, "FastDetector::detect: 8-bit gray image of the constructor's size expected");
+        std::vector<dr3hip_corner> cells(grid_occupancy_.size());
+        Context& c = Context::instance(device_);
+        c.check(dr3hip_fast_detect(c.get(), static_cast<const uint8_t*>(img_lvl_0.data), w_, h_, (int)img_lvl_0.step, n_pyr_levels_,
+                                   cell_size_, 20, detection_threshold, grid_occupancy_.data(), DR3HIP_HALF_REF_X86, cells.data()),
+                "FastDetector::detect");
+        for (std::size_t k = 0; k < cells.size(); ++k)
+            if (cells[k].level >= 0) { Corner q; q.x = cells[k].x; q.y = cells[k].y; q.level = cells[k].level; q.score = cells[k].score; corners.push_back(q); }
+        reset_grid();                                                                            // :95
+    }
+    int grid_n_cols() const { return grid_n_cols_; }
+    int grid_n_rows() const { return grid_n_rows_; }
+private:
+    int w_, h_, cell_size_, n_pyr_levels_, device_, grid_n_cols_, grid_n_rows_;
+    std::vector<unsigned char> grid_occupancy_;
+};
 
 // reconstruct::Panorama::paste_images / add_img_to_canvas / normalize_canvas (src/panorama.cpp:143-229).
 // The reference's `cv::Mat weighted_panorama` (CV_32FC4, zeros(_W x _H), :144) becomes a device-resident

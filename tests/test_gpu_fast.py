@@ -1,0 +1,69 @@
+"""FAST-10 score map, 3x3 non-max and grid-best Shi-Tomasi selection on the GPU vs the oracle's restatement of
+feature_detection::FastDetector::detect (reference src/features.cpp:43-98, src/utils.cpp:282-321).  Integer
+scores are bit-exact; the f32 Shi-Tomasi scores are bit-exact as well (exact integer sums, same scalar tail)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _corner_rich(synth, w, h, seed):
+    """analytic texture + random rectangles: plenty of FAST corners on every pyramid level"""
+    rng = np.random.default_rng(seed)
+    img = synth.frame_pair(w, h)[0].astype(np.int16)
+    for _ in range(w * h // 900):
+        x, y = int(rng.integers(0, w - 4)), int(rng.integers(0, h - 4))
+        ww, hh = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+        img[y:y + hh, x:x + ww] += int(rng.integers(-90, 90))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(1241, 376), (640, 480), (101, 67), (64, 16)])
+def test_fast10_score_map_bit_exact(dr3, O, ctx, synth, w, h):
+    img = _corner_rich(synth, w, h, w + h)
+    want = O.fast10_score_map(img, 20)
+    got = ctx.fast_score_map(img, 20)
+    assert np.array_equal(got, want)
+    assert (want > 0).sum() > (20 if w > 200 else 0)
+    noise = np.random.default_rng(1).integers(0, 256, (h, w), dtype=np.uint8)       # extreme contrast: scores up to 254
+    assert np.array_equal(ctx.fast_score_map(noise, 35), O.fast10_score_map(noise, 35))
+
+
+@pytest.mark.parametrize("w,h,levels,cell", [(1241, 376, 3, 30), (640, 480, 3, 30), (1920, 1080, 5, 20), (203, 131, 2, 25)])
+def test_fast_detect_grid_matches_oracle(dr3, O, ctx, synth, w, h, levels, cell):
+    img = _corner_rich(synth, w, h, 7 * w + h)
+    pyr = O.halfsample_pyramid(img, levels, O.HALF_REF_X86)
+    ox, oy, osc, ol = O.fast_detect_grid(pyr, cell, 20, 20.0)
+    gx, gy, gsc, gl = ctx.fast_detect(img, levels, cell, 20, 20.0)
+    assert np.array_equal(gl, ol)
+    m = ol >= 0
+    assert m.sum() > 0.5 * len(ol)
+    assert np.array_equal(gx[m], ox[m]) and np.array_equal(gy[m], oy[m])
+    assert np.array_equal(gsc[m].view(np.uint32), osc[m].view(np.uint32))
+    assert len(np.unique(ol[m])) >= 2                   # corners from several pyramid levels
+
+
+def test_fast_detect_respects_occupancy_and_threshold(dr3, O, ctx, synth):
+    img = _corner_rich(synth, 640, 480, 3)
+    pyr = O.halfsample_pyramid(img, 3, O.HALF_REF_X86)
+    gc, gr = -(-640 // 30), -(-480 // 30)
+    occ = (np.arange(gc * gr) % 3 == 0).astype(np.uint8)              # Detector::flag_features_grid
+    for thr in (20.0, 150.0):
+        o = O.fast_detect_grid(pyr, 30, 20, thr, occ)
+        g = ctx.fast_detect(img, 3, 30, 20, thr, occ)
+        assert np.array_equal(g[3], o[3]) and not (g[3][occ == 1] >= 0).any()
+        m = o[3] >= 0
+        assert np.array_equal(g[0][m], o[0][m]) and np.array_equal(g[1][m], o[1][m]) and np.array_equal(g[2][m].view(np.uint32), o[2][m].view(np.uint32))
+        assert (g[2][m] > thr).all()
+
+
+def test_detected_corners_feed_the_tracker(dr3, O, ctx, synth):
+    """Init::process_first_frame -> process_second_frame (src/initialization.cpp:552-613): detect on A, track into B"""
+    A, B, T = synth.frame_pair(640, 400)
+    x, y, sc, lv = ctx.fast_detect(A, 3, 30, 20, 20.0)
+    pts = np.stack([x[lv >= 0], y[lv >= 0]], 1).astype(np.float32)
+    assert len(pts) > 50
+    p = dr3.lk_params(win=(21, 21), max_level=3, max_iters=30, eps=0.01)
+    xy, st, err, _ = ctx.calcOpticalFlowPyrLK(A, B, pts, None, p)
+    gt = synth.apply_T(T, pts)
+    assert st.mean() > 0.9 and np.median(np.abs(xy - gt)[st == 1]) < 0.1
