@@ -64,6 +64,61 @@ def test_config2_shape_15x15_4lvl_2000pts(dr3, O, synth, ctx):
     _check_pair(dr3, O, ctx, A, B, pts, pg, po)
 
 
+def test_config5_shape_1080p_21x21_5lvl_5000pts(dr3, O, synth, ctx):
+    """BASELINE configs[4] shape: 1920x1080 pair, 5000 corners, 5-level pyr (maxLevel 4), 21x21 window"""
+    A, B, T = synth.frame_pair(1920, 1080, motion=synth.HD_MOTION)
+    pts = synth.grid_points(1920, 1080, 20, n=5000)
+    assert len(pts) == 5000
+    pg, po = _params(dr3, O, win=(21, 21), max_level=4, max_iters=30, eps=0.01)
+    g_xy, g_st, _, _, _ = _check_pair(dr3, O, ctx, A, B, pts, pg, po)
+    assert dr3.lk_effective_max_level(1920, 1080, 21, 21, 4) == 4
+    ok = g_st == 1
+    assert ok.mean() > 0.9 and np.median(np.abs(g_xy - synth.apply_T(T, pts))[ok]) < 0.05
+
+
+def test_full_batch_properties_at_bench_size(dr3, O, synth, ctx):
+    """configs[1] at the bench's launch shape (256 pairs x 2000 points): size-independent properties instead of
+    the oracle -- (i) pairs built from the same two frames give identical results whatever slot they sit in,
+    (ii) a frame tracked against itself has zero flow, (iii) rebuilding the pyramids is idempotent."""
+    B_ = 256
+    w, h = synth.KITTI_W, synth.KITTI_H
+    frames, _ = synth.frame_stream(3, w, h)
+    pts = synth.grid_points(w, h, 15, n=2000)
+    n = len(pts)
+    pg = dr3.lk_params(win=(15, 15), max_level=3, max_iters=30, eps=0.01)
+    seq = [frames[i % 3] for i in range(B_ + 1)]                        # pair i = (seq[i], seq[i+1]): period 3
+    b = dr3.FrameBatch(ctx, w, h, win=(15, 15), max_level=3, capacity=B_ + 1)
+    bufs = []
+    try:
+        for s0 in range(0, B_ + 1, 64):
+            b.upload(s0, np.stack(seq[s0:s0 + 64]))
+        b.build(0, B_ + 1, True)
+        P = np.ascontiguousarray(np.broadcast_to(pts[None], (B_, n, 2)), np.float32)
+        d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+        d_st, d_err = ctx.alloc(B_ * n), ctx.alloc(B_ * n * 4)
+        bufs = [d_prev, d_next, d_st, d_err]
+        b.track(B_, 0, d_prev, d_next, n, d_st, d_err, pg)
+        ctx.sync()
+        xy = d_next.download((B_, n, 2), np.float32); st = d_st.download((B_, n), np.uint8)
+        for i in range(3, B_):                                          # (i) period-3 pairs repeat bit for bit
+            assert np.array_equal(xy[i], xy[i - 3]) and np.array_equal(st[i], st[i - 3]), i
+        lvl0 = b.download_image(5, 3).copy(); der0 = b.download_deriv(5, 0).copy()
+        b.build(0, B_ + 1, True)                                        # (iii)
+        assert np.array_equal(b.download_image(5, 3), lvl0) and np.array_equal(b.download_deriv(5, 0), der0)
+        # (ii) identical frames in consecutive slots: zero flow, every point kept or lost identically
+        b.upload(1, seq[0]); b.build(1, 1, True)
+        d_next.upload(P)
+        b.track(1, 0, d_prev, d_next, n, d_st, d_err, pg)
+        ctx.sync()
+        xy0 = d_next.download((B_, n, 2), np.float32)[0]; st0 = d_st.download((B_, n), np.uint8)[0]
+        # zero mismatch -> zero update; the position only goes through the level rescaling (x / 2^L ... * 2)
+        assert np.abs(xy0[st0 == 1] - pts[st0 == 1]).max() < TOL_PX and st0.mean() > 0.95
+    finally:
+        for d in bufs:
+            d.free()
+        b.close()
+
+
 def test_reference_literals_30x30_maxlevel4(dr3, O, synth, ctx):
     """the literals of src/initialization.cpp:593-613: 30x30, maxLevel 4 (-> 3 at KITTI size),
     1000 iterations (clamped to 100), eps 1e-3, USE_INITIAL_FLOW with identity guess (:578)"""
