@@ -241,43 +241,6 @@ def main(argv=None):
     # full-size launch so that every launch rocprofv3 averages for this kernel has the same shape.
     batch.build(0, B + 1, True)
 
-    # ---- RCCL broadcast of a reference frame's pyramid through the library's own communicator
-    # (untimed; N > 1 over real GPUs only -- RCCL refuses ranks that share a device).  A failure is reported
-    # in the JSON line, it does not void the throughput measurement, which needs no collective.
-    ref_bcast = None
-    if dist.pg and backend == "nccl":
-        # every torch.distributed call below runs on every rank whatever happened locally, so a rank that
-        # failed cannot leave the others waiting in a collective
-        err, moved, ms, got = None, 0, 0.0, 0.0
-        try:
-            uid_root = ctx.comm_unique_id() if dist.rank == 0 else b"\0" * dr3.COMM_ID_BYTES
-        except Exception as e:                                   # noqa: BLE001
-            uid_root, err = b"\0" * dr3.COMM_ID_BYTES, str(e)
-        uid = dist.bcast_bytes(uid_root, dr3.COMM_ID_BYTES)
-        if dist.max_over_ranks(1.0 if err else 0.0) == 0.0:      # the root has an id: all ranks enter the init
-            try:
-                ctx.comm_init(uid, dist.world, dist.rank)
-                if dist.rank != 0:                               # receivers start from zeroed planes
-                    batch.upload(0, np.zeros_like(frames[0])); batch.build(0, 1, True)
-                sync()
-                ctx.timer_start()
-                moved = batch.bcast_slot(0, root=0, with_deriv=True)
-                ms = ctx.timer_stop()
-                got = float(batch.download_image(0, levels - 1).astype(np.int64).sum()
-                            + np.abs(batch.download_deriv(0, 0).astype(np.int64)).sum())
-                ctx.comm_destroy()
-            except Exception as e:                               # noqa: BLE001 -- reported, not fatal
-                err = str(e)
-        n_err = dist.sum_over_ranks(1.0 if err else 0.0)
-        hi, lo, ms_max = dist.max_over_ranks(got), -dist.max_over_ranks(-got), dist.max_over_ranks(ms)
-        ref_bcast = {"bytes_per_rank": int(moved), "ms": ms_max, "identical_on_all_ranks": bool(n_err == 0 and hi == lo),
-                     "transport": "RCCL ncclBroadcast x %d in one group (dr3hip_batch_bcast_slot)" % (2 * levels),
-                     "ranks_with_error": int(n_err), "error": (err or "")[:300] or None}
-        if dist.rank != 0:                                       # put this rank's own frame 0 back
-            batch.upload(0, frames[0])
-        batch.build(0, 1, True)
-        sync()
-
     def step():
         batch.build(1, B, True)                                  # pyramid + gradient pass, B new frames
         batch.track(B, 0, d_prev, d_next, N_PTS, d_st, d_err, params)   # B pairs x 2000 points
@@ -310,6 +273,19 @@ def main(argv=None):
     warp = None
     if not args.no_warp:
         warp = warp_leg(dist, ctx, dr3, synth, sync, steps=max(3, min(args.steps, 10)))
+
+    # ---- RCCL broadcast of a reference frame's pyramid through the library's own communicator.
+    # Untimed, after every measurement, N > 1 over real GPUs only (RCCL refuses ranks that share a device), and under
+    # a watchdog: a communicator that cannot come up must cost the run this one sub-object, not its JSON line.
+    ref_bcast, leg_hung = None, False
+    if dist.pg and backend == "nccl" and os.environ.get("DR3_BENCH_NO_REF_BCAST") != "1":
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(r=ref_bcast_leg(dist, ctx, dr3, batch, frames, levels, sync)), daemon=True)
+        th.start()
+        th.join(float(os.environ.get("DR3_BENCH_REF_BCAST_TIMEOUT", "120")))
+        leg_hung = th.is_alive()
+        ref_bcast = {"error": "timed out (communicator bootstrap or broadcast did not complete)"} if leg_hung else box.get("r")
 
     # ---- CPU baseline (rank 0 only, bounded sample) -----------------------------------------------------
     cpu = None
@@ -366,12 +342,46 @@ def main(argv=None):
         }
         print(json.dumps(out), flush=True)
 
+    if leg_hung:                 # a thread is still inside RCCL: no orderly teardown is possible
+        sys.stdout.flush()
+        os._exit(0)
     for d in (d_prev, d_next, d_st, d_err):
         d.free()
     batch.close()
     ctx.close()
     dist.close()
     return 0
+
+
+def ref_bcast_leg(dist, ctx, dr3, batch, frames, levels, sync):
+    """rank 0 builds slot 0, dr3hip_batch_bcast_slot sends it to every rank, every rank checks it holds the same
+    planes.  Every torch.distributed call runs on every rank whatever happened locally, so a rank that failed
+    cannot leave the others waiting in a collective."""
+    err, moved, ms, got = None, 0, 0.0, 0.0
+    try:
+        uid_root = ctx.comm_unique_id() if dist.rank == 0 else b"\0" * dr3.COMM_ID_BYTES
+    except Exception as e:                                       # noqa: BLE001
+        uid_root, err = b"\0" * dr3.COMM_ID_BYTES, str(e)
+    uid = dist.bcast_bytes(uid_root, dr3.COMM_ID_BYTES)
+    if dist.max_over_ranks(1.0 if err else 0.0) == 0.0:          # the root has an id: all ranks enter the init
+        try:
+            ctx.comm_init(uid, dist.world, dist.rank)
+            batch.upload(0, frames[0] if dist.rank == 0 else np.zeros_like(frames[0]))   # receivers start from zeros
+            batch.build(0, 1, True)
+            sync()
+            ctx.timer_start()
+            moved = batch.bcast_slot(0, root=0, with_deriv=True)
+            ms = ctx.timer_stop()
+            got = float(batch.download_image(0, levels - 1).astype(np.int64).sum()
+                        + np.abs(batch.download_deriv(0, 0).astype(np.int64)).sum())
+            ctx.comm_destroy()
+        except Exception as e:                                   # noqa: BLE001 -- reported, not fatal
+            err = str(e)
+    n_err = dist.sum_over_ranks(1.0 if err else 0.0)
+    hi, lo, ms_max = dist.max_over_ranks(got), -dist.max_over_ranks(-got), dist.max_over_ranks(ms)
+    return {"bytes_per_rank": int(moved), "ms": ms_max, "identical_on_all_ranks": bool(n_err == 0 and hi == lo and hi > 0),
+            "transport": "RCCL ncclBroadcast x %d in one group (dr3hip_batch_bcast_slot)" % (2 * levels),
+            "ranks_with_error": int(n_err), "error": (err or "")[:300] or None}
 
 
 def warp_leg(dist, ctx, dr3, synth, sync, steps):
