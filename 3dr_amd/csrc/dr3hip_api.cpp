@@ -397,6 +397,26 @@ int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int
     for (int i = 0; i < 9; ++i) a.M[i] = j.M[i];
     a.bw0 = j.bw0; a.bw0_shift = j.bw0_shift; a.fast = j.fast;
     a.cx0 = min_x < 0 ? 0 : min_x; a.cx1 = max_x > cw ? cw : max_x; a.min_x = min_x;
+    // The reference walks every canvas row of the box columns; rows whose samples are all border-0 change nothing
+    // (:205-207).  A canvas pixel samples the image only if its source coordinate lies within 1 px of it, so the
+    // forward image of the rectangle grown by 1.5 px (a convex quadrilateral while W stays positive), grown by
+    // another 2 canvas rows, bounds the rows that can change; anything doubtful keeps all rows.
+    a.cy0 = 0; a.cy1 = ch;
+    {
+        const double cxs[2] = {-1.5, w + 0.5}, cys[2] = {-1.5, h + 0.5};
+        double ylo = INFINITY, yhi = -INFINITY; bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) for (int k = 0; k < 2 && ok; ++k) {
+            const double W = (double)M[6] * cxs[i] + (double)M[7] * cys[k] + (double)M[8];
+            const double Y = ((double)M[3] * cxs[i] + (double)M[4] * cys[k] + (double)M[5]) / W;
+            if (!(W > 1e-9) || !std::isfinite(Y)) ok = false;
+            ylo = std::fmin(ylo, Y); yhi = std::fmax(yhi, Y);
+        }
+        if (ok && j.fast) {                        // j.fast: W of one sign and bounded away from 0 over the whole canvas
+            const double lo = std::floor(ylo) - 2.0, hi = std::ceil(yhi) + 3.0;
+            a.cy0 = lo < 0.0 ? 0 : (lo > ch ? ch : (int)lo);
+            a.cy1 = hi > ch ? ch : (hi < 0.0 ? 0 : (int)hi);
+        }
+    }
     a.ramp = (const float*)ctx->stage[6].p;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PANO_ADD, pe);
     HIPCHK(ctx, launch_panorama_add(a, ctx->stream));

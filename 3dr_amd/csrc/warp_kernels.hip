@@ -447,12 +447,16 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
 // taps equal the 32FC4 copy's), with the 32FC4 arithmetic of the warp (f32 table weights, 4-term sum, no
 // FMA), multiplies by ramp[x - min_x] and does the 16-byte read-modify-write.  Bytes per canvas pixel in
 // the box: 3 read (image) + 16 + 16 (canvas) instead of 16 + 16 (warp) + 32 + 32 (feather pass).
+#ifndef DR3_PANO_LOG
+#define DR3_PANO_LOG 6
+#endif
 template <bool GENERIC>
 __global__ __launch_bounds__(256) void panorama_add_kernel(const PanoAddArgs a)
 {
-    const int x = a.cx0 + blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= a.cx1 || y >= a.ch) return;
+    // wave tile (1 << DR3_PANO_LOG) x (64 >> DR3_PANO_LOG) canvas pixels, 4 waves stacked in y
+    const int x = a.cx0 + blockIdx.x * (1 << DR3_PANO_LOG) + (threadIdx.x & ((1 << DR3_PANO_LOG) - 1));
+    const int y = a.cy0 + (blockIdx.y * 4 + threadIdx.y) * (64 >> DR3_PANO_LOG) + (threadIdx.x >> DR3_PANO_LOG);
+    if (x >= a.cx1 || y >= a.cy1) return;
     double M[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) M[i] = a.M[i];
@@ -626,9 +630,10 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
 
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s)
 {
-    if (a.cx1 <= a.cx0 || a.ch <= 0) return hipSuccess;
+    if (a.cx1 <= a.cx0 || a.cy1 <= a.cy0) return hipSuccess;
     dim3 block(64, 4);
-    dim3 grid((a.cx1 - a.cx0 + 63) / 64, (a.ch + 3) / 4, 1);
+    const int tw = 1 << DR3_PANO_LOG, th = 4 * (64 >> DR3_PANO_LOG);
+    dim3 grid((a.cx1 - a.cx0 + tw - 1) / tw, (a.cy1 - a.cy0 + th - 1) / th, 1);
     if (a.bw0_shift < 0) hipLaunchKernelGGL(panorama_add_kernel<true>,  grid, block, 0, s, a);
     else                 hipLaunchKernelGGL(panorama_add_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();
