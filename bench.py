@@ -126,7 +126,7 @@ def aggregate_rate(dist, units_this_rank, elapsed_max):
 # ----------------------------------------------------------------------------------------------
 # algorithmic bytes
 # ----------------------------------------------------------------------------------------------
-def pmc_traffic(kernel_substr, batch):
+def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json"):
     """HBM bytes per launch of one kernel from the newest committed PMC summary (profiles/*/pmc_traffic.json,
     made by tools/profile_bench.sh + tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same script; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).
@@ -137,11 +137,11 @@ def pmc_traffic(kernel_substr, batch):
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
         for d in sorted(os.listdir(root), reverse=True):
-            f = os.path.join(root, d, "pmc_traffic.json")
+            f = os.path.join(root, d, fname)
             if os.path.exists(f):
                 for name, t in json.load(open(f))["kernels"].items():
                     if kernel_substr in name and "hbm_bytes" in t:
-                        return t["hbm_bytes"], "profiles/%s/pmc_traffic.json" % d
+                        return t["hbm_bytes"], "profiles/%s/%s" % (d, fname)
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -415,11 +415,12 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
         mpix = aggregate_rate(dist, NT_ * TW_ * TH_ * steps / 1e6, el)
         k_ms = ms / max(n, 1)
         alg = NT_ * TW_ * TH_ * 2 * esz                  # esz read + esz written per dst pixel
+        traffic, tsrc = pmc_traffic("warp_perspective_kernel<%d," % typ, 256, "pmc_traffic_warp.json")
         res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms,
                      "roofline": {"kernel": "warp_perspective_kernel<%s>" % name.upper(), "bound": "hbm",
                                   "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                                  "algorithmic_bytes_per_launch": alg}}
+                                  "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                                  "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg}}
         for d in srcs + dsts:
             d.free()
     res["workload"] = "configs[2]: 8 tiles 4000x3000, per-pixel homography, bilinear, border 0"
@@ -472,10 +473,12 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
             "add_kernel_ms": add_ms, "box_pixels_per_step": box_px,
             "roofline_add": {"kernel": "panorama_add_kernel", "bound": "hbm", "achieved": alg_add / (add_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_add / (add_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": None, "algorithmic_bytes_per_launch": alg_add},
+                             "traffic": pmc_traffic("panorama_add_kernel", 256, "pmc_traffic_warp.json")[0],
+                             "algorithmic_bytes_per_launch": alg_add},
             "roofline_normalize": {"kernel": "panorama_normalize_kernel", "bound": "hbm", "achieved": alg_norm / (norm_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_norm / (norm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                   "traffic": None, "algorithmic_bytes_per_launch": alg_norm, "kernel_ms": norm_ms},
+                                   "traffic": pmc_traffic("panorama_normalize_kernel", 256, "pmc_traffic_warp.json")[0],
+                                   "algorithmic_bytes_per_launch": alg_norm, "kernel_ms": norm_ms},
             "replaces": "reference passes per tile: 32FC4 copy (3 r + 16 w), warp onto the full canvas (16 r + 16 w per canvas px), "
                         "feather + accumulate (32 r + 32 w per box px)"}
 

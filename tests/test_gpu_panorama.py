@@ -76,3 +76,29 @@ def test_normalize_truncation_order(dr3, O, ctx):
     d_c.free(); d_o.free()
     assert np.array_equal(got, O.normalize_canvas(canvas))
     assert not got[5].any() and not got[6].any()
+
+
+def test_bad_arguments_return_errors(dr3, ctx):
+    """error behaviour of the new entry points: negative codes + text, nothing thrown across the ABI"""
+    img = np.zeros((20, 30, 3), np.uint8)
+    d_img, d_c, d_o = ctx.to_device(img), ctx.alloc(40 * 50 * 16), ctx.alloc(40 * 50 * 3)
+    try:
+        M = np.eye(3, dtype=np.float32)
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.panorama_add(d_img, 30, 20, 10, d_c, 50, 40, 50 * 16, M, 5)              # image stride < 3 w
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.panorama_add(d_img, 30, 20, 90, d_c, 50, 40, 50 * 16 + 4, M, 5)          # canvas rows not 16-byte aligned
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.panorama_add(d_img, 1, 20, 90, d_c, 50, 40, 50 * 16, M, 5)               # 1-column box: the reference throws
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.panorama_normalize(d_c, 50, 40, 50 * 16, d_o, 100)                       # output stride < 3 w
+        with pytest.raises(dr3.Dr3HipError):
+            ctx._warp_local(img, 7, 100.0)                                               # unknown map kind
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.fast_detect(np.zeros((4, 4), np.uint8))                                  # smaller than the FAST ring
+        with pytest.raises(dr3.Dr3HipError):
+            ctx.fast_detect(np.zeros((64, 64), np.uint8), fast_threshold=0)
+        assert ctx.fast_detect(np.zeros((64, 64), np.uint8))[3].max() == -1             # flat image: no feature at all
+    finally:
+        for d in (d_img, d_c, d_o):
+            d.free()
