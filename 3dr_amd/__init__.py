@@ -113,6 +113,7 @@ def _signatures():
         "dr3hip_fast_grid_size": ([ip, ip, ip, P(ip), P(ip)], ip),
         "dr3hip_fast_detect": ([vp, vp, ip, ip, ip, ip, ip, ip, C.c_double, vp, ip, P(Corner)], ip),
         "dr3hip_fast_score_map": ([vp, vp, ip, ip, ip, ip, vp], ip),
+        "dr3hip_check_fundamental": ([vp, vp, ip, vp, vp, ip, C.c_float, vp, vp], ip),
         "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_warp_local_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
@@ -269,6 +270,17 @@ class Context:
                                            float(detection_threshold), None if occ is None else _p(occ), int(mode), cells))
         a = np.frombuffer(cells, dtype=np.dtype([("x", np.int32), ("y", np.int32), ("level", np.int32), ("score", np.float32)]))
         return a["x"].copy(), a["y"].copy(), a["score"].copy(), a["level"].copy()
+
+    def check_fundamental(self, F21, pts1, pts2, sigma=1.0, want_inliers=True):
+        """InitHelper::CheckFundamental (src/initialization.cpp:171-249) for all hypotheses: F21 (n_hyp, 3, 3)"""
+        F = np.ascontiguousarray(F21, np.float32).reshape(-1, 9)
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        assert len(p1) == len(p2)
+        scores = np.zeros(len(F), np.float32)
+        inl = np.zeros((len(F), len(p1)), np.uint8) if want_inliers else None
+        self._chk(lib().dr3hip_check_fundamental(self.h, _p(F), len(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(scores),
+                                                 None if inl is None else _p(inl)))
+        return scores, inl
 
     def warp_spherical(self, img, f):
         """utils::warp_spherical (src/utils.cpp:196-201): map generation fused with the remap"""

@@ -326,6 +326,37 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
     return n_feat;
 }
 
+// ---- CheckFundamental over all hypotheses ----------------------------------------------------
+int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const float* pts1, const float* pts2,
+                             int n, float sigma, float* scores, uint8_t* inliers)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!F21 || !pts1 || !pts2 || !scores || n_hyp < 1 || n < 0 || n_hyp > (1 << 20) || n > (1 << 24))
+        return fail(ctx, DR3HIP_EINVAL, "check_fundamental: bad arguments");
+    DeviceGuard g(ctx->device);
+    const size_t fb = sizeof(float) * 9 * (size_t)n_hyp, pb = sizeof(float) * 2 * (size_t)(n ? n : 1);
+    const size_t sb = sizeof(float) * (size_t)n_hyp, ib = inliers ? (size_t)n_hyp * (size_t)(n ? n : 1) : 0;
+    int rc;
+    if ((rc = stage_reserve(ctx, 0, fb + 256)) || (rc = stage_reserve(ctx, 2, 2 * pb + 256)) || (rc = stage_reserve(ctx, 3, sb + 256)) ||
+        (ib && (rc = stage_reserve(ctx, 1, ib + 256)))) return rc;
+    uint8_t* dp = (uint8_t*)ctx->stage[2].p;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[0].p, F21, fb, hipMemcpyHostToDevice, ctx->stream));
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(dp, pts1, pb, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dp + pb, pts2, pb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CheckFArgs a;
+    a.F = (const float*)ctx->stage[0].p; a.n_hyp = n_hyp;
+    a.pts1 = (const float*)dp; a.pts2 = (const float*)(dp + pb); a.n = n;
+    a.inv_sigma_square = (float)(1.0 / (double)(sigma * sigma));          // const float invSigmaSquare = 1.0/(sigma*sigma) (:190)
+    a.scores = (float*)ctx->stage[3].p; a.inliers = ib ? (uint8_t*)ctx->stage[1].p : nullptr;
+    HIPCHK(ctx, launch_check_fundamental(a, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(scores, a.scores, sb, hipMemcpyDeviceToHost, ctx->stream));
+    if (ib && n) HIPCHK(ctx, hipMemcpyAsync(inliers, a.inliers, ib, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
 // ---- panorama paste -------------------------------------------------------------------------
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags);      // defined with the warp entry points below

@@ -87,6 +87,14 @@ struct FastArgs {          // FAST-10 score map + grid-best selection of one pyr
     unsigned long long* cells;                    // device, per cell: (score bits << 32) | ~raster order
 };
 
+struct CheckFArgs {        // InitHelper::CheckFundamental for n_hyp matrices (fast_kernels.hip)
+    const float* F; int n_hyp;                    // n_hyp x 9, row-major
+    const float* pts1; const float* pts2; int n;  // n x 2 each
+    float inv_sigma_square;
+    float* scores;                                // n_hyp
+    uint8_t* inliers;                             // n_hyp x n or null
+};
+
 struct RemapArgs {
     const uint8_t* src; int sw, sh, sstride;
     uint8_t* dst;       int dw, dh, dstride;
@@ -110,6 +118,7 @@ hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
+hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);

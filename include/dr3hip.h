@@ -214,6 +214,14 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
 int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int fast_threshold,
                           uint8_t* score_map);
 
+/* ---- post-LK geometry vote ---------------------------------------------------------------- */
+/* InitHelper::CheckFundamental (reference src/initialization.cpp:171-249) for every RANSAC hypothesis of
+ * FindFundamental (:80-127) in one launch.  F21: n_hyp x 9 f32 row-major (T2t * Fn * T1 as at :115);
+ * pts1 / pts2: the n matched keypoints (kp1.pt, kp2.pt) as x,y f32 pairs; sigma as mSigma.
+ * scores: n_hyp f32 out; inliers: n_hyp x n u8 out or NULL.  Host buffers. */
+int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const float* pts1, const float* pts2,
+                             int n, float sigma, float* scores, uint8_t* inliers);
+
 /* ---- spherical / cylindrical pre-warp ------------------------------------------------- */
 /* utils::warp_spherical / warp_cylindrical (reference src/utils.cpp:196-201, :267-272): map generation
  * (compute_spherical_warping :125-187, compute_cylindrical_warping :203-265) fused with warp_local's

@@ -610,6 +610,37 @@ int dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int 
     return n;
 }
 
+/* src/initialization.cpp:171-249 */
+float dr3o_check_fundamental(const float F21[9], const float* pts1, const float* pts2, int n, float sigma, uint8_t* inliers)
+{
+    const float f11 = F21[0], f12 = F21[1], f13 = F21[2], f21 = F21[3], f22 = F21[4], f23 = F21[5], f31 = F21[6], f32 = F21[7], f33 = F21[8];
+    const float th = 3.841, thScore = 5.991;
+    const float invSigmaSquare = 1.0 / (sigma * sigma);
+    float score = 0;
+    int i;
+    for (i = 0; i < n; ++i) {
+        int bIn = 1;
+        const float u1 = pts1[2 * i], v1 = pts1[2 * i + 1], u2 = pts2[2 * i], v2 = pts2[2 * i + 1];
+        const float a2 = f11 * u1 + f12 * v1 + f13;
+        const float b2 = f21 * u1 + f22 * v1 + f23;
+        const float c2 = f31 * u1 + f32 * v1 + f33;
+        const float num2 = a2 * u2 + b2 * v2 + c2;
+        const float squareDist1 = num2 * num2 / (a2 * a2 + b2 * b2);
+        const float chiSquare1 = squareDist1 * invSigmaSquare;
+        float a1, b1, c1, num1, squareDist2, chiSquare2;
+        if (chiSquare1 > th) bIn = 0; else score += thScore - chiSquare1;
+        a1 = f11 * u2 + f21 * v2 + f31;
+        b1 = f12 * u2 + f22 * v2 + f32;
+        c1 = f13 * u2 + f23 * v2 + f33;
+        num1 = a1 * u1 + b1 * v1 + c1;
+        squareDist2 = num1 * num1 / (a1 * a1 + b1 * b1);
+        chiSquare2 = squareDist2 * invSigmaSquare;
+        if (chiSquare2 > th) bIn = 0; else score += thScore - chiSquare2;
+        if (inliers) inliers[i] = (uint8_t)bIn;
+    }
+    return score;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* A-4 / A-5  warpPerspective, remap                                                          */
 /* ------------------------------------------------------------------------------------------ */

@@ -128,6 +128,11 @@ int  dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int
                            int cell_size, int fast_threshold, double detection_threshold, const uint8_t* occupancy,
                            int* cell_x, int* cell_y, float* cell_score, int* cell_level);
 
+/* InitHelper::CheckFundamental (src/initialization.cpp:171-249): symmetric epipolar chi-square score of one
+ * fundamental matrix F21 (row-major f32) over n matched points (pts1 = kp1.pt, pts2 = kp2.pt as x,y f32 pairs);
+ * inliers (n bytes, may be NULL).  f32 arithmetic exactly as written, sequential score accumulation. */
+float dr3o_check_fundamental(const float F21[9], const float* pts1, const float* pts2, int n, float sigma, uint8_t* inliers);
+
 /* src/utils.cpp:125-187 / :203-265 -- spherical / cylindrical map generation (u,v f32 planes w*h) */
 void dr3o_spherical_map(int w, int h, float f, float* u, float* v);
 void dr3o_cylindrical_map(int w, int h, float f, float* u, float* v);

@@ -79,6 +79,8 @@ def lib():
         L.dr3o_fast_nonmax_3x3.restype = ip
         L.dr3o_fast_detect_grid.argtypes = [vp, vp, ip, ip, ip, ip, ip, C.c_double, vp, vp, vp, vp, vp]
         L.dr3o_fast_detect_grid.restype = ip
+        L.dr3o_check_fundamental.argtypes = [vp, vp, vp, ip, C.c_float, vp]
+        L.dr3o_check_fundamental.restype = C.c_float
         L.dr3o_panorama_bbox.argtypes = [vp, ip, ip, vp, vp, vp, vp]
         L.dr3o_panorama_bbox.restype = None
         L.dr3o_feather_ramp.argtypes = [ip, ip, ip, vp]
@@ -325,3 +327,12 @@ def fast_detect_grid(pyr, cell_size=30, fast_threshold=20, detection_threshold=2
     if r < 0:
         raise MemoryError("dr3o_fast_detect_grid")
     return cx, cy, cs, cl
+
+
+def check_fundamental(F21, pts1, pts2, sigma=1.0):
+    """InitHelper::CheckFundamental (src/initialization.cpp:171-249) -> (score f32, inliers u8[n])"""
+    F = np.ascontiguousarray(F21, np.float32).reshape(9)
+    p1 = np.ascontiguousarray(pts1, np.float32); p2 = np.ascontiguousarray(pts2, np.float32)
+    inl = np.zeros(len(p1), np.uint8)
+    sc = lib().dr3o_check_fundamental(_p(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(inl))
+    return np.float32(sc), inl

@@ -67,3 +67,32 @@ def test_detected_corners_feed_the_tracker(dr3, O, ctx, synth):
     xy, st, err, _ = ctx.calcOpticalFlowPyrLK(A, B, pts, None, p)
     gt = synth.apply_T(T, pts)
     assert st.mean() > 0.9 and np.median(np.abs(xy - gt)[st == 1]) < 0.1
+
+
+def test_check_fundamental_all_hypotheses_bit_exact(dr3, O, ctx, synth):
+    """InitHelper::CheckFundamental (src/initialization.cpp:171-249) over the 200 RANSAC hypotheses of FindFundamental:
+    scores (sequential f32 sums) and inlier masks equal the oracle bit for bit"""
+    rng = np.random.default_rng(17)
+    n = 1500
+    p1 = np.stack([rng.uniform(8, 1233, n), rng.uniform(8, 368, n)], 1).astype(np.float32)
+    # a plausible epipolar geometry: pure forward motion + small rotation, plus noise and 20 % outliers
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]])
+    t = np.array([0.05, -0.02, 1.0]); tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    a = 0.01; R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Ftrue = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    depth = rng.uniform(5, 60, n)
+    X = (np.linalg.inv(K) @ np.c_[p1, np.ones(n)].T) * depth
+    x2 = K @ (R @ X + t[:, None]); p2 = (x2[:2] / x2[2]).T + rng.normal(0, 0.4, (n, 2))
+    out = rng.random(n) < 0.2
+    p2[out] += rng.uniform(-40, 40, (int(out.sum()), 2))
+    p2 = p2.astype(np.float32)
+    Fs = np.stack([(Ftrue / np.linalg.norm(Ftrue) + rng.normal(0, s, (3, 3)) * 1e-6) for s in np.linspace(0, 3, 200)]).astype(np.float32)
+    for sigma in (1.0, 2.5):
+        scores, inl = ctx.check_fundamental(Fs, p1, p2, sigma)
+        for h in range(len(Fs)):
+            o_sc, o_in = O.check_fundamental(Fs[h], p1, p2, sigma)
+            assert scores[h].view(np.uint32) == o_sc.view(np.uint32), (h, scores[h], o_sc)
+            assert np.array_equal(inl[h], o_in), h
+        assert scores[0] > 0.99 * scores.max() and scores[-1] < 0.8 * scores.max() and inl[0].mean() > 0.6
+    sc, none = ctx.check_fundamental(Fs[:3], p1[:0], p2[:0], 1.0)            # no matches: score 0
+    assert np.array_equal(sc, np.zeros(3, np.float32))
