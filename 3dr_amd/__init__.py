@@ -32,6 +32,7 @@ MAX_LEVELS, MAX_WIN = 8, 32
 PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM = 0, 1, 2, 3, 4, 5, 6, 7
 COMM_ID_BYTES = 128
 WARP_SPHERICAL, WARP_CYLINDRICAL = 1, 2
+NO_POINT = np.float32(-1.0e6)
 
 
 class Dr3HipError(RuntimeError):
@@ -112,6 +113,7 @@ def _signatures():
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
         "dr3hip_fast_grid_size": ([ip, ip, ip, P(ip), P(ip)], ip),
         "dr3hip_fast_detect": ([vp, vp, ip, ip, ip, ip, ip, ip, C.c_double, vp, ip, P(Corner)], ip),
+        "dr3hip_batch_detect": ([vp, ip, ip, ip, ip, ip, C.c_double, ip, vp, vp], ip),
         "dr3hip_fast_score_map": ([vp, vp, ip, ip, ip, ip, vp], ip),
         "dr3hip_check_fundamental": ([vp, vp, ip, vp, vp, ip, C.c_float, vp, vp], ip),
         "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
@@ -469,6 +471,13 @@ class FrameBatch:
 
     def build(self, first, count, with_deriv=True):
         self.ctx._chk(lib().dr3hip_batch_build(self.h, first, count, int(with_deriv)))
+
+    def detect(self, first, count, n_levels=3, cell_size=30, fast_threshold=20, detection_threshold=20.0, mode=HALF_REF_X86,
+               d_xy=None, d_corners=None):
+        """batched FastDetector::detect on slots first..first+count-1; returns n_cells (device outputs in d_xy / d_corners)"""
+        ptr = lambda x: None if x is None else (x.ptr if isinstance(x, DeviceBuffer) else x)
+        return self.ctx._chk(lib().dr3hip_batch_detect(self.h, int(first), int(count), int(n_levels), int(cell_size), int(fast_threshold),
+                                                       float(detection_threshold), int(mode), ptr(d_xy), ptr(d_corners)))
 
     def bcast_slot(self, slot, root=0, with_deriv=True):
         """RCCL broadcast of one slot's pyramid (+ derivative pyramid) from `root`; returns bytes moved"""

@@ -41,6 +41,10 @@ struct dr3hip_batch {
     int w = 0, h = 0, win_w = 0, win_h = 0, levels = 0, capacity = 0;
     LevelDev lv[DR3HIP_MAX_LEVELS];
     size_t bytes = 0;
+    // detector storage (dr3hip_batch_detect), allocated on first use: half-sample pyramid levels 1.. of every
+    // slot (continuous rows like the reference's cv::Mat levels), one score map and one cell-key array per slot
+    struct Det { int n_levels = 0, n_cells = 0; uint8_t* hs[8] = {nullptr}; long long hs_step[8] = {0};
+                 uint8_t* score = nullptr; long long score_step = 0; int spitch = 0; unsigned long long* keys = nullptr; } det;
 };
 
 static std::string g_init_err;
@@ -246,6 +250,7 @@ int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int
     a.img = (const uint8_t*)ctx->stage[4].p; a.w = w; a.h = h; a.stride = ip;
     a.score = (uint8_t*)ctx->stage[1].p; a.spitch = ip; a.threshold = fast_threshold;
     a.level = 0; a.cell_size = 1; a.grid_cols = 1; a.det_threshold = 0.f; a.occupancy = nullptr; a.cells = nullptr;
+    a.n_slots = 1; a.img_step = 0; a.score_step = 0; a.n_cells = 0;
     HIPCHK(ctx, launch_fast_score(a, ctx->stream));
     HIPCHK(ctx, hipMemcpy2DAsync(score_map, w, a.score, ip, w, h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -302,6 +307,7 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
         a.score = (uint8_t*)ctx->stage[1].p; a.spitch = sp; a.threshold = fast_threshold;
         a.level = l; a.cell_size = cell_size; a.grid_cols = gc; a.det_threshold = thr_f;
         a.occupancy = occupancy ? d_occ : nullptr; a.cells = d_cells;
+        a.n_slots = 1; a.img_step = 0; a.score_step = 0; a.n_cells = n_cells;
         HIPCHK(ctx, launch_fast_score(a, ctx->stream));
         HIPCHK(ctx, launch_fast_select(a, ctx->stream));
     }
@@ -324,6 +330,98 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
         ++n_feat;
     }
     return n_feat;
+}
+
+static int resolve_half_mode(int mode, int w);        // defined with the half-sampler entry points below
+
+// Device-resident, batched detector on frame slots: the front end of a stream (Frame::Frame -> create_img_pyramid ->
+// FastDetector::detect, reference src/frame.cpp:13-20, :57) without a host hop; its points feed dr3hip_batch_track.
+int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int cell_size, int fast_threshold,
+                        double detection_threshold, int halfsample_mode, float* d_xy, dr3hip_corner* d_corners)
+{
+    if (!b) return DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    const int w = b->w, h = b->h;
+    if (first < 0 || count < 1 || first + count > b->capacity || n_levels < 1 || n_levels > 8 || cell_size < 1 ||
+        fast_threshold < 1 || fast_threshold > 254 || w >= 16384 || h >= 16384 || (w >> (n_levels - 1)) < 1 || (h >> (n_levels - 1)) < 1 ||
+        (!d_xy && !d_corners) || halfsample_mode < 0 || halfsample_mode > 3)
+        return fail(ctx, DR3HIP_EINVAL, "batch_detect: bad arguments");
+    const float thr_f = (float)detection_threshold;
+    if (!(thr_f >= 0.f)) return fail(ctx, DR3HIP_EINVAL, "batch_detect: detection_threshold must be >= 0");
+    int gc, gr;
+    dr3hip_fast_grid_size(w, h, cell_size, &gc, &gr);
+    const int n_cells = gc * gr;
+    DeviceGuard g(ctx->device);
+    dr3hip_batch::Det& D = b->det;
+    if (D.n_levels < n_levels || D.n_cells < n_cells) {               // (re)allocate the detector storage
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int l = 0; l < 8; ++l) if (D.hs[l]) { (void)hipFree(D.hs[l]); D.hs[l] = nullptr; }
+        if (D.score) { (void)hipFree(D.score); D.score = nullptr; }
+        if (D.keys) { (void)hipFree(D.keys); D.keys = nullptr; }
+        D.n_levels = 0; D.n_cells = 0;
+        int lw = w, lh = h;
+        for (int l = 1; l < n_levels; ++l) {
+            lw /= 2; lh /= 2;
+            D.hs_step[l] = (long long)align_up(lw * lh + 64, 256);
+            void* p = nullptr;
+            if (hipMalloc(&p, (size_t)D.hs_step[l] * b->capacity + 256) != hipSuccess) return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (level %d)", l);
+            D.hs[l] = (uint8_t*)p; b->bytes += (size_t)D.hs_step[l] * b->capacity + 256;
+        }
+        D.spitch = align_up(w, 64);
+        D.score_step = (long long)align_up(D.spitch * h, 256);
+        void *ps = nullptr, *pk = nullptr;
+        if (hipMalloc(&ps, (size_t)D.score_step * b->capacity + 256) != hipSuccess ||
+            hipMalloc(&pk, sizeof(unsigned long long) * (size_t)n_cells * b->capacity) != hipSuccess) {
+            if (ps) (void)hipFree(ps);
+            return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (score map / cells)");
+        }
+        D.score = (uint8_t*)ps; D.keys = (unsigned long long*)pk;
+        b->bytes += (size_t)D.score_step * b->capacity + 256 + sizeof(unsigned long long) * (size_t)n_cells * b->capacity;
+        D.n_levels = n_levels; D.n_cells = n_cells;
+    }
+    // cell keys start as Corner(0, 0, detection_threshold, 0) with the lowest tie rank (src/features.cpp:49)
+    uint32_t thr_bits; memcpy(&thr_bits, &thr_f, 4);
+    const unsigned long long empty_key = ((unsigned long long)thr_bits << 32) | 0xffffffffull;
+    unsigned long long* keys = D.keys + (size_t)first * n_cells;
+    {
+        // every 8 bytes carry the same value: fill through a tiny staged pattern instead of a host vector per slot
+        std::vector<unsigned long long> init((size_t)n_cells * count, empty_key);
+        HIPCHK(ctx, hipMemcpyAsync(keys, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_FAST, pe);
+    // half-sample pyramid of every slot: level 0 is the slot's frame inside its pitched plane; the reference holds it as
+    // a continuous cv::Mat (step == cols), which is what REF_SCALAR's flat walk must see (lstride)
+    int lw = w, lh = h;
+    for (int l = 1; l < n_levels; ++l) {
+        HalfArgs ha;
+        ha.src = (l == 1) ? b->lv[0].img + (size_t)b->lv[0].step * first : D.hs[l - 1] + (size_t)D.hs_step[l - 1] * first;
+        ha.w = lw; ha.h = lh; ha.sstride = (l == 1) ? b->lv[0].pitch : lw; ha.lstride = lw;
+        ha.dst = D.hs[l] + (size_t)D.hs_step[l] * first; ha.ow = lw / 2; ha.oh = lh / 2; ha.dstride = lw / 2;
+        ha.mode = resolve_half_mode(halfsample_mode, lw);
+        ha.n_slots = count; ha.sstep = (l == 1) ? b->lv[0].step : D.hs_step[l - 1]; ha.dstep = D.hs_step[l];
+        HIPCHK(ctx, launch_halfsample(ha, ctx->stream));
+        lw /= 2; lh /= 2;
+    }
+    lw = w; lh = h;
+    for (int l = 0; l < n_levels; ++l) {
+        FastArgs a;
+        a.img = (l == 0) ? b->lv[0].img + (size_t)b->lv[0].step * first : D.hs[l] + (size_t)D.hs_step[l] * first;
+        a.w = lw; a.h = lh; a.stride = (l == 0) ? b->lv[0].pitch : lw;
+        a.img_step = (l == 0) ? b->lv[0].step : D.hs_step[l];
+        a.score = D.score + (size_t)D.score_step * first; a.spitch = D.spitch; a.score_step = D.score_step;
+        a.threshold = fast_threshold; a.level = l; a.cell_size = cell_size; a.grid_cols = gc; a.det_threshold = thr_f;
+        a.occupancy = nullptr; a.cells = keys; a.n_slots = count; a.n_cells = n_cells;
+        HIPCHK(ctx, launch_fast_score(a, ctx->stream));
+        HIPCHK(ctx, launch_fast_select(a, ctx->stream));
+        lw /= 2; lh /= 2;
+    }
+    CellsArgs ca;
+    ca.cells = keys; ca.n_total = n_cells * count; ca.empty_key = empty_key; ca.det_threshold = thr_f;
+    ca.xy = d_xy; ca.corners = d_corners;
+    HIPCHK(ctx, launch_cells_decode(ca, ctx->stream));
+    prof_end(ctx, pe);
+    return n_cells;
 }
 
 // ---- CheckFundamental over all hypotheses ----------------------------------------------------
@@ -692,7 +790,10 @@ void dr3hip_batch_destroy(dr3hip_batch* b)
     for (int l = 0; l < DR3HIP_MAX_LEVELS; ++l) {
         if (b->lv[l].img) (void)hipFree(b->lv[l].img);
         if (b->lv[l].der) (void)hipFree(b->lv[l].der);
+        if (b->det.hs[l]) (void)hipFree(b->det.hs[l]);
     }
+    if (b->det.score) (void)hipFree(b->det.score);
+    if (b->det.keys) (void)hipFree(b->det.keys);
     if (b->ctx->lk_batch == b) b->ctx->lk_batch = nullptr;
     delete b;
 }
@@ -888,6 +989,7 @@ int dr3hip_halfsample_dev(dr3hip_ctx* ctx, const uint8_t* d_src, int w, int h, i
     a.src = d_src; a.w = w; a.h = h; a.sstride = sstride;
     a.dst = d_dst; a.ow = w / 2; a.oh = h / 2; a.dstride = dstride;
     a.mode = resolve_half_mode(mode, w);
+    a.lstride = sstride; a.n_slots = 1; a.sstep = 0; a.dstep = 0;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_HALF, pe);
     HIPCHK(ctx, launch_halfsample(a, ctx->stream));
     prof_end(ctx, pe);

@@ -85,6 +85,9 @@ struct FastArgs {          // FAST-10 score map + grid-best selection of one pyr
     float det_threshold;                          // (float)detection_threshold: the initial Corner score of every cell
     const uint8_t* occupancy;                     // device, grid cells, may be null
     unsigned long long* cells;                    // device, per cell: (score bits << 32) | ~raster order
+    int n_slots;                                  // grid z: frames (0 or 1: a single image)
+    long long img_step, score_step;               // bytes between frames
+    int n_cells;                                  // cells (and occupancy bytes) per frame
 };
 
 struct CheckFArgs {        // InitHelper::CheckFundamental for n_hyp matrices (fast_kernels.hip)
@@ -93,6 +96,14 @@ struct CheckFArgs {        // InitHelper::CheckFundamental for n_hyp matrices (f
     float inv_sigma_square;
     float* scores;                                // n_hyp
     uint8_t* inliers;                             // n_hyp x n or null
+};
+
+struct CellsArgs {         // decode the per-cell keys of fast_select_kernel into corners / tracker input points
+    const unsigned long long* cells; int n_total; // n_slots * n_cells
+    unsigned long long empty_key;                 // the initial key: the cell holds no feature
+    float det_threshold;
+    float* xy;                                    // n_total x 2, level-0 pixels, or (DR3HIP_NO_POINT, DR3HIP_NO_POINT); may be null
+    dr3hip_corner* corners;                       // n_total, may be null
 };
 
 struct RemapArgs {
@@ -109,6 +120,9 @@ struct HalfArgs {
     const uint8_t* src; int w, h, sstride;
     uint8_t* dst;       int ow, oh, dstride;
     int mode;           // DR3HIP_HALF_TRUNC / _SSE2 / _REF_SCALAR (REF_X86 resolved on the host)
+    int lstride;        // the step of the cv::Mat the reference would hold (REF_SCALAR's flat walk); == sstride unless pitched
+    int n_slots;        // grid z: frames, sstep / dstep bytes apart (0 or 1: a single image)
+    long long sstep, dstep;
 };
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
@@ -118,6 +132,7 @@ hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
+hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);

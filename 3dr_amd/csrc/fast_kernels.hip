@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void fast10_score_kernel(const FastArgs a)
     if (x >= a.w || y >= a.h) return;
     uint8_t out = 0;
     if (x >= 3 && y >= 3 && x < a.w - 3 && y < a.h - 3) {             // fast_corner_detect_10 scans [3, size - 3)
-        const uint8_t* p = a.img + (long long)y * a.stride + x;
+        const uint8_t* p = a.img + (long long)blockIdx.z * a.img_step + (long long)y * a.stride + x;
         const int c = p[0];
         int d[16], e[16];
 #pragma unroll
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void fast10_score_kernel(const FastArgs a)
         const int score = max(max_arc10(d), max_arc10(e)) - 1;
         if (score >= a.threshold) out = (uint8_t)score;               // <= 254
     }
-    a.score[(long long)y * a.spitch + x] = out;
+    a.score[(long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x] = out;
 }
 
 // utils::shi_tomasi_score, reference src/utils.cpp:282-321
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= a.w || y >= a.h) return;
-    const uint8_t* sp = a.score + (long long)y * a.spitch + x;
+    const uint8_t* sp = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x;
     const int s = sp[0];
     if (s == 0) return;
 #pragma unroll
@@ -100,12 +100,34 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
         }
     const int scale = 1 << a.level;
     const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
-    if (a.occupancy && a.occupancy[k]) return;
-    const float score = shi_tomasi(a.img, a.w, a.h, a.stride, x, y);
+    if (a.occupancy && a.occupancy[(long long)blockIdx.z * a.n_cells + k]) return;
+    const float score = shi_tomasi(a.img + (long long)blockIdx.z * a.img_step, a.w, a.h, a.stride, x, y);
     if (!(score > a.det_threshold)) return;                           // can never beat the cell's initial Corner
     const uint32_t order = ((uint32_t)a.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
     const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)~order;
-    atomicMax(a.cells + k, key);
+    atomicMax(a.cells + (long long)blockIdx.z * a.n_cells + k, key);
+}
+
+// per-cell keys -> Corner(x * scale, y * scale, score, level) (src/features.cpp:78-93) and the tracker's input points
+__global__ __launch_bounds__(256) void cells_decode_kernel(const CellsArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_total) return;
+    const unsigned long long key = a.cells[i];
+    const uint32_t order = ~(uint32_t)key;
+    const float score = __uint_as_float((uint32_t)(key >> 32));
+    const bool valid = key != a.empty_key && (double)score > (double)a.det_threshold;
+    const int level = (int)(order >> 28);
+    const int x = (int)(order & 0x3fffu) << level, y = (int)((order >> 14) & 0x3fffu) << level;
+    if (a.corners) {
+        dr3hip_corner c;
+        c.x = valid ? x : 0; c.y = valid ? y : 0; c.level = valid ? level : -1; c.score = valid ? score : a.det_threshold;
+        a.corners[i] = c;
+    }
+    if (a.xy) {
+        a.xy[2 * i]     = valid ? (float)x : DR3HIP_NO_POINT;
+        a.xy[2 * i + 1] = valid ? (float)y : DR3HIP_NO_POINT;
+    }
 }
 
 // InitHelper::CheckFundamental (reference src/initialization.cpp:171-249) for all RANSAC hypotheses of
@@ -146,10 +168,17 @@ hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s)
+{
+    if (a.n_total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_decode_kernel, dim3((a.n_total + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, 1);
+    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(fast10_score_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -157,7 +186,7 @@ hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, 1);
+    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(fast_select_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -547,23 +547,31 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;    // 4 output pixels per lane
     const int Y = blockIdx.y * 4 + threadIdx.y;
     if (X >= a.ow || Y >= a.oh) return;
+    const uint8_t* __restrict__ src = a.src + (long long)blockIdx.z * a.sstep;      // grid z = frame slot
+    uint8_t* __restrict__ dst = a.dst + (long long)blockIdx.z * a.dstep;
     uint32_t o[4] = {0, 0, 0, 0};
     if (a.mode == DR3HIP_HALF_REF_SCALAR) {
-        // reference pointer walk: flat offset of output (Y, X) is Y*(2*ow + stride) + 2*X
-        const long long total = (long long)a.sstride * a.h;
+        // reference pointer walk: flat offset of output (Y, X) is Y*(2*ow + stride) + 2*X, where stride is the
+        // step of the cv::Mat the reference holds (a.lstride); the bytes may sit in a wider-pitched plane here
+        const int ls = a.lstride;
+        const long long total = (long long)ls * a.h;
+        auto at = [&](long long i) -> int {
+            if (i >= total) return 0;
+            if (ls == a.sstride) return src[i];
+            const long long r = i / ls;
+            return src[r * a.sstride + (i - r * ls)];
+        };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (X + k < a.ow) {
-                const long long t = (long long)Y * (2LL * a.ow + a.sstride) + 2LL * (X + k), b = t + a.sstride;
-                const int p = t < total ? a.src[t] : 0, q = t + 1 < total ? a.src[t + 1] : 0;
-                const int r = b < total ? a.src[b] : 0, s = b + 1 < total ? a.src[b + 1] : 0;
-                o[k] = half_px(p, q, r, s, DR3HIP_HALF_TRUNC);
+                const long long t = (long long)Y * (2LL * a.ow + ls) + 2LL * (X + k), b = t + ls;
+                o[k] = half_px(at(t), at(t + 1), at(b), at(b + 1), DR3HIP_HALF_TRUNC);
             }
         }
     } else {
-        const uint8_t* r0 = a.src + (long long)(2 * Y) * a.sstride + 2 * X;
+        const uint8_t* r0 = src + (long long)(2 * Y) * a.sstride + 2 * X;
         const uint8_t* r1 = r0 + a.sstride;
-        const bool fast = (X + 3 < a.ow) && (((reinterpret_cast<uintptr_t>(a.src) | (uintptr_t)a.sstride) & 7) == 0);
+        const bool fast = (X + 3 < a.ow) && (((reinterpret_cast<uintptr_t>(src) | (uintptr_t)a.sstride) & 7) == 0);
         if (fast) {
             const uint2 t = *reinterpret_cast<const uint2*>(r0), b = *reinterpret_cast<const uint2*>(r1);
             const uint32_t tw[2] = {t.x, t.y}, bw[2] = {b.x, b.y};
@@ -578,8 +586,8 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
                 if (X + k < a.ow) o[k] = half_px(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1], a.mode);
         }
     }
-    uint8_t* drow = a.dst + (long long)Y * a.dstride;
-    if (X + 3 < a.ow && ((reinterpret_cast<uintptr_t>(a.dst) | (uintptr_t)a.dstride) & 3) == 0) {
+    uint8_t* drow = dst + (long long)Y * a.dstride;
+    if (X + 3 < a.ow && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)a.dstride) & 3) == 0) {
         *reinterpret_cast<uint32_t*>(drow + X) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
     } else {
 #pragma unroll
@@ -652,7 +660,7 @@ hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s)
 {
     if (a.ow <= 0 || a.oh <= 0) return hipSuccess;
     dim3 block(64, 4);
-    dim3 grid((a.ow + 255) / 256, (a.oh + 3) / 4, 1);
+    dim3 grid((a.ow + 255) / 256, (a.oh + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(halfsample_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

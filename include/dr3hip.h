@@ -210,6 +210,16 @@ int dr3hip_fast_grid_size(int w, int h, int cell_size, int* grid_cols, int* grid
 int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int n_levels,
                        int cell_size, int fast_threshold, double detection_threshold,
                        const uint8_t* occupancy, int halfsample_mode, dr3hip_corner* cells);
+/* Device-resident, batched form on the frame slots of a dr3hip_batch (the front end of a stream: pyramid ->
+ * detect -> track without a host hop).  For slots first..first+count-1: half-sample pyramid of the slot's frame,
+ * FAST + non-max + grid-best selection on every level, then per cell either the corner or "no feature".
+ * d_xy (device, count x n_cells x 2 f32, may be NULL): level-0 pixel positions in dr3hip_batch_track's layout; cells
+ * without a feature hold DR3HIP_NO_POINT, which the tracker reports with status 0.
+ * d_corners (device, count x n_cells dr3hip_corner, may be NULL).  Enqueued on the ctx stream.
+ * Returns n_cells (grid_cols * grid_rows) or < 0. */
+#define DR3HIP_NO_POINT (-1.0e6f)
+int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int cell_size, int fast_threshold,
+                        double detection_threshold, int halfsample_mode, float* d_xy, dr3hip_corner* d_corners);
 /* the FAST-10 score map of one image alone (tests, tooling): score_map w*h u8, 0 = no corner */
 int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int stride, int fast_threshold,
                           uint8_t* score_map);

@@ -96,3 +96,55 @@ def test_check_fundamental_all_hypotheses_bit_exact(dr3, O, ctx, synth):
         assert scores[0] > 0.99 * scores.max() and scores[-1] < 0.8 * scores.max() and inl[0].mean() > 0.6
     sc, none = ctx.check_fundamental(Fs[:3], p1[:0], p2[:0], 1.0)            # no matches: score 0
     assert np.array_equal(sc, np.zeros(3, np.float32))
+
+
+def test_batch_detect_matches_host_detect_and_feeds_the_tracker(dr3, O, ctx, synth):
+    """device-resident front end (dr3hip_batch_detect): per slot the same cells as the host-image entry point and the
+    oracle -- including the odd-width KITTI shape, where the reference's half-sampler walks the level-0 image as a
+    continuous cv::Mat while the slot plane is pitched -- and its point array drives dr3hip_batch_track directly"""
+    w, h, n_fr = 1241, 376, 3
+    frames = [_corner_rich(synth, w, h, 40 + i) for i in range(n_fr)]
+    frames[1] = np.roll(frames[0], (1, 2), axis=(0, 1))                  # slot 1 = slot 0 moved by (+2, +1) px
+    b = dr3.FrameBatch(ctx, w, h, win=(15, 15), max_level=3, capacity=n_fr)
+    bufs = []
+    try:
+        b.upload(0, np.stack(frames))
+        b.build(0, n_fr, True)
+        gc, gr = -(-w // 30), -(-h // 30)
+        n_cells = gc * gr
+        d_xy = ctx.alloc(n_fr * n_cells * 8); d_c = ctx.alloc(n_fr * n_cells * 16)
+        bufs = [d_xy, d_c]
+        assert b.detect(0, n_fr, 3, 30, 20, 20.0, d_xy=d_xy, d_corners=d_c) == n_cells
+        ctx.sync()
+        xy = d_xy.download((n_fr, n_cells, 2), np.float32)
+        cor = d_c.download((n_fr, n_cells), np.dtype([("x", np.int32), ("y", np.int32), ("level", np.int32), ("score", np.float32)]))
+        for i in range(n_fr):
+            gx, gy, gs, gl = ctx.fast_detect(frames[i], 3, 30, 20, 20.0)
+            ox, oy, os_, ol = O.fast_detect_grid(O.halfsample_pyramid(frames[i], 3, O.HALF_REF_X86), 30, 20, 20.0)
+            assert np.array_equal(cor["level"][i], ol) and np.array_equal(gl, ol)
+            m = ol >= 0
+            assert m.sum() > 300
+            assert np.array_equal(cor["x"][i][m], ox[m]) and np.array_equal(cor["y"][i][m], oy[m])
+            assert np.array_equal(cor["score"][i][m].view(np.uint32), os_[m].view(np.uint32))
+            assert np.array_equal(xy[i][m], np.stack([ox[m], oy[m]], 1).astype(np.float32))
+            assert (xy[i][~m] == dr3.NO_POINT).all()
+        # track slot 0 -> slot 1 from the detected points, no host hop
+        d_next = ctx.alloc(n_cells * 8); d_st = ctx.alloc(n_cells); d_err = ctx.alloc(n_cells * 4)
+        bufs += [d_next, d_st, d_err]
+        d_next.upload(xy[0])
+        p = dr3.lk_params(win=(15, 15), max_level=3, max_iters=30, eps=0.01)
+        b.track(1, 0, d_xy, d_next, n_cells, d_st, d_err, p)
+        ctx.sync()
+        st = d_st.download((n_cells,), np.uint8); nxt = d_next.download((n_cells, 2), np.float32)
+        m = cor["level"][0] >= 0
+        assert not st[~m].any()                                          # "no feature" cells come back lost
+        ok = m & (st == 1)
+        assert ok.sum() > 0.8 * m.sum()
+        assert np.median(np.abs(nxt[ok] - (xy[0][ok] + np.array([2, 1], np.float32)))) < 0.05
+        o_xy, o_st, _, _ = O.lk_track(frames[0], frames[1], xy[0][m], None, O.lk_params(win=(15, 15), max_level=3, max_iters=30, eps=0.01),
+                                      order=O.ORDER_WAVE64)
+        assert np.array_equal(st[m], o_st) and np.array_equal(nxt[m].view(np.uint32), o_xy.view(np.uint32))
+    finally:
+        for d in bufs:
+            d.free()
+        b.close()
