@@ -288,16 +288,13 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
     uint8_t* base = (uint8_t*)ctx->stage[4].p;
     uint8_t* d_occ = (uint8_t*)ctx->stage[6].p;
     unsigned long long* d_cells = (unsigned long long*)(d_occ + cells_off);
-    // every cell starts as Corner(0, 0, detection_threshold, 0) (src/features.cpp:49): score bits of the
-    // threshold with the lowest tie rank, so only a strictly greater score replaces it
+    // every cell starts as Corner(0, 0, detection_threshold, 0) (src/features.cpp:49) and only a strictly greater score
+    // replaces it: the kernel pushes keys for scores > threshold only, so "no key yet" can be the all-zero pattern
     const float thr_f = (float)detection_threshold;
     if (!(thr_f >= 0.f)) return fail(ctx, DR3HIP_EINVAL, "fast_detect: detection_threshold must be >= 0");
-    uint32_t thr_bits; memcpy(&thr_bits, &thr_f, 4);
-    std::vector<unsigned long long> init((size_t)n_cells, ((unsigned long long)thr_bits << 32) | 0xffffffffull);
-    HIPCHK(ctx, hipMemcpyAsync(d_cells, init.data(), sizeof(unsigned long long) * (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_cells, 0, sizeof(unsigned long long) * (size_t)n_cells, ctx->stream));
     if (occupancy) HIPCHK(ctx, hipMemcpyAsync(d_occ, occupancy, (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(base + off[0], img, (size_t)stride * (h - 1) + w, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                   // init is a local
     for (int l = 1; l < n_levels; ++l)
         if ((rc = dr3hip_halfsample_dev(ctx, base + off[l - 1], lw[l - 1], lh[l - 1], lp[l - 1], base + off[l], lp[l], halfsample_mode))) return rc;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_FAST, pe);
@@ -320,7 +317,7 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
         dr3hip_corner& c = cells[k];
         const uint32_t bits = (uint32_t)(keys[k] >> 32), order = ~(uint32_t)keys[k];
         memcpy(&c.score, &bits, 4);
-        if (keys[k] == init[0] || !((double)c.score > detection_threshold)) {         // :88 corner.score > detection_threshold
+        if (keys[k] == 0ull || !((double)c.score > detection_threshold)) {             // :88 corner.score > detection_threshold
             c.x = 0; c.y = 0; c.level = -1; c.score = thr_f;
             continue;
         }
@@ -379,16 +376,10 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
         b->bytes += (size_t)D.score_step * b->capacity + 256 + sizeof(unsigned long long) * (size_t)n_cells * b->capacity;
         D.n_levels = n_levels; D.n_cells = n_cells;
     }
-    // cell keys start as Corner(0, 0, detection_threshold, 0) with the lowest tie rank (src/features.cpp:49)
-    uint32_t thr_bits; memcpy(&thr_bits, &thr_f, 4);
-    const unsigned long long empty_key = ((unsigned long long)thr_bits << 32) | 0xffffffffull;
+    // cell keys: all-zero = still the initial Corner(0, 0, detection_threshold, 0) (src/features.cpp:49); the select
+    // kernel pushes a key only for a score strictly above the threshold
     unsigned long long* keys = D.keys + (size_t)first * n_cells;
-    {
-        // every 8 bytes carry the same value: fill through a tiny staged pattern instead of a host vector per slot
-        std::vector<unsigned long long> init((size_t)n_cells * count, empty_key);
-        HIPCHK(ctx, hipMemcpyAsync(keys, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    HIPCHK(ctx, hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)n_cells * count, ctx->stream));
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_FAST, pe);
     // half-sample pyramid of every slot: level 0 is the slot's frame inside its pitched plane; the reference holds it as
     // a continuous cv::Mat (step == cols), which is what REF_SCALAR's flat walk must see (lstride)
@@ -417,7 +408,7 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
         lw /= 2; lh /= 2;
     }
     CellsArgs ca;
-    ca.cells = keys; ca.n_total = n_cells * count; ca.empty_key = empty_key; ca.det_threshold = thr_f;
+    ca.cells = keys; ca.n_total = n_cells * count; ca.empty_key = 0ull; ca.det_threshold = thr_f;
     ca.xy = d_xy; ca.corners = d_corners;
     HIPCHK(ctx, launch_cells_decode(ca, ctx->stream));
     prof_end(ctx, pe);

@@ -3,13 +3,13 @@
 // utils::shi_tomasi_score src/utils.cpp:282-321) for gfx950.  SURVEY 8f.2: this is what produces the
 // points the LK tracker consumes.  The `fast` library the reference links (CMakeLists.txt:17) is not
 // vendored; its published algorithm is restated here ("FAST"), parity unpinned.
-//   fast10_score_kernel : one lane per pixel.  The library finds the score by bisection over the corner
+//   fast10_score_kernel : one lane per 4 pixels (compass quick-rejection from dword loads).  The library finds the score by bisection over the corner
 //                         test; the fixed point of that search has a closed form -- the largest b for which
 //                         10 contiguous ring pixels are all > p + b (or all < p - b) is
 //                         max over the 16 arcs of min over the arc of (ring - p) (resp. p - ring), minus 1 --
 //                         evaluated with a doubling sliding minimum (windows 2, 4, 8, 10).  A pixel is a
 //                         corner at threshold t iff that score is >= t.
-//   fast_select_kernel  : one lane per pixel of the score map: 3x3 non-max (a corner falls when an adjacent
+//   fast_select_kernel  : one lane per 8 bytes of the score map; per corner: 3x3 non-max (a corner falls when an adjacent
 //                         corner scores >= it), occupancy test, Shi-Tomasi score of the 8x8 box (integer
 //                         sums are exact in the reference's f32 accumulators: 64 * 255^2 < 2^24), then a
 //                         64-bit atomicMax per grid cell on (score bits, ~raster order): the reference keeps
@@ -35,29 +35,102 @@ __device__ __forceinline__ int max_arc10(const int v[16])
     return best;
 }
 
+// full ring score of one pixel (closed form of the library's bisection), c = centre value
+__device__ __forceinline__ int ring_score(const uint8_t* __restrict__ p, int stride, int c)
+{
+    int d[16], e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int dy = (i < 2 || i == 15) ? 3 : (i == 2 || i == 14) ? 2 : (i == 3 || i == 13) ? 1 : (i == 4 || i == 12) ? 0
+                     : (i == 5 || i == 11) ? -1 : (i == 6 || i == 10) ? -2 : -3;
+        const int dx = (i == 0 || i == 8) ? 0 : (i == 1 || i == 7) ? 1 : (i == 2 || i == 6) ? 2 : (i >= 3 && i <= 5) ? 3
+                     : (i == 9 || i == 15) ? -1 : (i == 10 || i == 14) ? -2 : -3;
+        d[i] = (int)p[dy * stride + dx] - c;
+        e[i] = -d[i];
+    }
+    return max(max_arc10(d), max_arc10(e)) - 1;
+}
+
+// rank of this lane among the set bits of a wave ballot, and the ballot's population
+__device__ __forceinline__ int ballot_rank(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// A wave owns 256 pixels of one row, a lane 4 adjacent ones (x % 4 == 0).
+//  1. Rosten's quick rejection: any 10 contiguous ring pixels contain at least two of the four compass pixels (ring
+//     positions 0, 4, 8, 12), so a corner at threshold t needs two of them > c + t or two < c - t.  The compass pixels
+//     of the lane's 4 pixels come from five aligned dword loads (rows y - 3, y + 3: one dword; row y: bytes x-4 .. x+7).
+//  2. The few survivors are compacted through LDS (ballot + mbcnt) so that the 16-pixel ring score runs on densely
+//     packed lanes -- once per 64 candidates instead of once per pixel slot with any candidate in the wave.
+//  3. Each lane collects its 4 result bytes from LDS and stores one dword of the score map.
 __global__ __launch_bounds__(256) void fast10_score_kernel(const FastArgs a)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= a.w || y >= a.h) return;
-    uint8_t out = 0;
-    if (x >= 3 && y >= 3 && x < a.w - 3 && y < a.h - 3) {             // fast_corner_detect_10 scans [3, size - 3)
-        const uint8_t* p = a.img + (long long)blockIdx.z * a.img_step + (long long)y * a.stride + x;
-        const int c = p[0];
-        int d[16], e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int dy = (i < 2 || i == 15) ? 3 : (i == 2 || i == 14) ? 2 : (i == 3 || i == 13) ? 1 : (i == 4 || i == 12) ? 0
-                         : (i == 5 || i == 11) ? -1 : (i == 6 || i == 10) ? -2 : -3;
-            const int dx = (i == 0 || i == 8) ? 0 : (i == 1 || i == 7) ? 1 : (i == 2 || i == 6) ? 2 : (i >= 3 && i <= 5) ? 3
-                         : (i == 9 || i == 15) ? -1 : (i == 10 || i == 14) ? -2 : -3;
-            d[i] = (int)p[dy * a.stride + dx] - c;
-            e[i] = -d[i];
+    __shared__ uint16_t s_cand[4][256];
+    __shared__ uint32_t s_res[4][64];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int xw = blockIdx.x * 256;
+    const int x = xw + lane * 4;
+    const int y = blockIdx.y * 4 + wv;
+    if (xw >= a.w || y >= a.h) return;                                   // wave-uniform
+    const uint8_t* __restrict__ img = a.img + (long long)blockIdx.z * a.img_step;
+    const uint8_t* row = img + (long long)y * a.stride;
+    const int t = a.threshold;
+    uint32_t cand = 0;                                                    // bit k: pixel x + k passed the quick test
+    if (y >= 3 && y < a.h - 3 && x < a.w) {                              // fast_corner_detect_10 scans [3, size - 3)
+        const bool wide = x >= 4 && x + 8 <= a.stride && (((uintptr_t)img | (uintptr_t)a.stride) & 3) == 0;   // dword loads stay in the row
+        uint32_t up = 0, dn = 0, lo = 0, mid = 0, hi = 0;
+        if (wide) {
+            up = *reinterpret_cast<const uint32_t*>(row - 3 * a.stride + x);
+            dn = *reinterpret_cast<const uint32_t*>(row + 3 * a.stride + x);
+            lo = *reinterpret_cast<const uint32_t*>(row + x - 4);
+            mid = *reinterpret_cast<const uint32_t*>(row + x);
+            hi = *reinterpret_cast<const uint32_t*>(row + x + 4);
         }
-        const int score = max(max_arc10(d), max_arc10(e)) - 1;
-        if (score >= a.threshold) out = (uint8_t)score;               // <= 254
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x + k;
+            if (xx < 3 || xx >= a.w - 3) continue;
+            int c, n0, n4, n8, n12;
+            if (wide) {
+                const uint64_t rowbits = ((uint64_t)hi << 32) | mid;    // bytes x .. x + 7
+                const uint64_t lobits = ((uint64_t)mid << 32) | lo;     // bytes x - 4 .. x + 3
+                c = (mid >> (8 * k)) & 0xff;
+                n0 = (int)((dn >> (8 * k)) & 0xff) - c;                 // ring 0:  (0, +3)
+                n8 = (int)((up >> (8 * k)) & 0xff) - c;                 // ring 8:  (0, -3)
+                n4 = (int)((rowbits >> (8 * (k + 3))) & 0xff) - c;      // ring 4:  (+3, 0)
+                n12 = (int)((lobits >> (8 * (k + 1))) & 0xff) - c;      // ring 12: (-3, 0)
+            } else {
+                const uint8_t* p = row + xx;
+                c = p[0]; n0 = (int)p[3 * a.stride] - c; n4 = (int)p[3] - c; n8 = (int)p[-3 * a.stride] - c; n12 = (int)p[-3] - c;
+            }
+            const int nb = (n0 > t) + (n4 > t) + (n8 > t) + (n12 > t), nd = (n0 < -t) + (n4 < -t) + (n8 < -t) + (n12 < -t);
+            if (nb >= 2 || nd >= 2) cand |= 1u << k;
+        }
     }
-    a.score[(long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x] = out;
+    // compaction: candidate (lane, k) -> dense slot
+    s_res[wv][lane] = 0u;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool c = (cand >> k) & 1u;
+        const unsigned long long m = __ballot(c);
+        if (c) s_cand[wv][total + ballot_rank(m)] = (uint16_t)(4 * lane + k);
+        total += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint8_t* res8 = reinterpret_cast<uint8_t*>(s_res[wv]);
+    for (int i = lane; i < total; i += 64) {
+        const int idx = s_cand[wv][i];
+        const uint8_t* p = row + xw + idx;
+        const int score = ring_score(p, a.stride, p[0]);
+        if (score >= t) res8[idx] = (uint8_t)score;                     // <= 254
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (x < a.w) {
+        uint8_t* orow = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x;
+        *reinterpret_cast<uint32_t*>(orow) = s_res[wv][lane];           // spitch is a multiple of 64 >= w: pad bytes become 0
+    }
 }
 
 // utils::shi_tomasi_score, reference src/utils.cpp:282-321
@@ -80,14 +153,9 @@ __device__ float shi_tomasi(const uint8_t* __restrict__ img, int w, int h, int s
     return (float)(0.5 * ((double)t - sqrt((double)disc)));
 }
 
-__global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
+// one surviving corner of the score map: non-max test, occupancy, Shi-Tomasi, per-cell atomicMax
+__device__ void select_pixel(const FastArgs& a, const uint8_t* __restrict__ sp, int x, int y, int s, int z)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= a.w || y >= a.h) return;
-    const uint8_t* sp = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x;
-    const int s = sp[0];
-    if (s == 0) return;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -100,12 +168,41 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
         }
     const int scale = 1 << a.level;
     const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
-    if (a.occupancy && a.occupancy[(long long)blockIdx.z * a.n_cells + k]) return;
-    const float score = shi_tomasi(a.img + (long long)blockIdx.z * a.img_step, a.w, a.h, a.stride, x, y);
+    if (a.occupancy && a.occupancy[(long long)z * a.n_cells + k]) return;
+    const float score = shi_tomasi(a.img + (long long)z * a.img_step, a.w, a.h, a.stride, x, y);
     if (!(score > a.det_threshold)) return;                           // can never beat the cell's initial Corner
     const uint32_t order = ((uint32_t)a.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
     const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)~order;
-    atomicMax(a.cells + (long long)blockIdx.z * a.n_cells + k, key);
+    atomicMax(a.cells + (long long)z * a.n_cells + k, key);
+}
+
+// scan of the score map: a wave owns 512 map bytes of one row, a lane 8 of them (rows are 64-byte pitched); the corners
+// found are compacted through LDS so that the non-max test and the 8x8 Shi-Tomasi box run on densely packed lanes
+__global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
+{
+    __shared__ uint16_t s_list[4][512];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int xw = blockIdx.x * 512;
+    const int x = xw + lane * 8;
+    const int y = blockIdx.y * 4 + wv;
+    if (xw >= a.w || y >= a.h) return;                                   // wave-uniform
+    const uint8_t* srow = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch;
+    uint2 v = make_uint2(0u, 0u);
+    if (x < a.w) v = *reinterpret_cast<const uint2*>(srow + x);
+    if (__ballot((v.x | v.y) != 0) == 0ull) return;                     // nothing in these 512 bytes
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool c = (((k < 4 ? v.x : v.y) >> (8 * (k & 3))) & 0xff) != 0 && x + k < a.w;
+        const unsigned long long m = __ballot(c);
+        if (c) s_list[wv][total + ballot_rank(m)] = (uint16_t)(8 * lane + k);
+        total += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < total; i += 64) {
+        const int xx = xw + s_list[wv][i];
+        select_pixel(a, srow + xx, xx, y, srow[xx], blockIdx.z);
+    }
 }
 
 // per-cell keys -> Corner(x * scale, y * scale, score, level) (src/features.cpp:78-93) and the tracker's input points
@@ -178,7 +275,7 @@ hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s)
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
+    dim3 block(64, 4), grid((a.w + 255) / 256, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(fast10_score_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -186,7 +283,7 @@ hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 63) / 64, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
+    dim3 block(64, 4), grid((a.w + 511) / 512, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(fast_select_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

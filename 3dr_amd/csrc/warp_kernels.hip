@@ -555,17 +555,19 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
         // step of the cv::Mat the reference holds (a.lstride); the bytes may sit in a wider-pitched plane here
         const int ls = a.lstride;
         const long long total = (long long)ls * a.h;
-        auto at = [&](long long i) -> int {
-            if (i >= total) return 0;
-            if (ls == a.sstride) return src[i];
-            const long long r = i / ls;
-            return src[r * a.sstride + (i - r * ls)];
-        };
+        // element i of the continuous walk = (row i / ls, column i % ls) of the pitched plane; one division per output
+        // pixel: i + 1 and i + ls follow from (row, column) by a carry
+        auto at = [&](long long i, long long r, int c) -> int { return i < total ? src[r * a.sstride + c] : 0; };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (X + k < a.ow) {
-                const long long t = (long long)Y * (2LL * a.ow + ls) + 2LL * (X + k), b = t + ls;
-                o[k] = half_px(at(t), at(t + 1), at(b), at(b + 1), DR3HIP_HALF_TRUNC);
+                const long long t = (long long)Y * (2LL * a.ow + ls) + 2LL * (X + k);
+                long long r; int c;
+                if (total < (1LL << 31)) { const uint32_t q = (uint32_t)t / (uint32_t)ls; r = q; c = (int)((uint32_t)t - q * (uint32_t)ls); }
+                else { r = t / ls; c = (int)(t - r * ls); }
+                const bool wrap = c + 1 == ls;                                  // t + 1 starts the next row
+                const long long r1 = wrap ? r + 1 : r; const int c1 = wrap ? 0 : c + 1;
+                o[k] = half_px(at(t, r, c), at(t + 1, r1, c1), at(t + ls, r + 1, c), at(t + ls + 1, r1 + 1, c1), DR3HIP_HALF_TRUNC);
             }
         }
     } else {

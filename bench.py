@@ -200,6 +200,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per step and per GPU")
     ap.add_argument("--no-warp", action="store_true", help="skip the configs[2] warp leg")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the detect -> track front-end leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args(argv)
@@ -269,6 +270,11 @@ def main(argv=None):
         g_st = d_st.download((B, N_PTS), np.uint8)[0]
         verified = bool(np.array_equal(g_xy, o_xy) and np.array_equal(g_st, o_st))
 
+    # ---- the whole front end on the device: pyramid + gradients, FAST detector, LK from the detected points -----
+    frontend = None
+    if not args.no_frontend:
+        frontend = frontend_leg(dist, ctx, dr3, batch, B, sync, max(3, min(args.steps, 10)))
+
     # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------
     warp = None
     if not args.no_warp:
@@ -336,6 +342,7 @@ def main(argv=None):
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "latency/issue-bound, not HBM-bound (SURVEY 8d): no roofline fraction claimed"},
+            "frontend": frontend,
             "warp": warp,
             "ref_pyramid_bcast": ref_bcast,
             "cpu_baseline": cpu,
@@ -351,6 +358,43 @@ def main(argv=None):
     ctx.close()
     dist.close()
     return 0
+
+
+def frontend_leg(dist, ctx, dr3, batch, B, sync, steps):
+    """Frame::Frame -> FastDetector::detect -> calcOpticalFlowPyrLK as one device-resident step over B frames (reference
+    src/frame.cpp:13-20, :57, src/initialization.cpp:552-613): LK pyramids + gradients, the reference's 3-level
+    half-sample pyramid with FAST-10 + grid-best Shi-Tomasi (cell 15 -> 83 x 26 = 2158 cells ~ configs[1]'s 2000
+    corners), then every frame's corners tracked into the next frame.  Untimed extra, not the headline metric."""
+    gc, gr = -(-batch.w // 15), -(-batch.h_px // 15)
+    n_cells = gc * gr
+    d_pts, d_next = ctx.alloc(B * n_cells * 8), ctx.alloc(B * n_cells * 8)
+    d_st, d_err = ctx.alloc(B * n_cells), ctx.alloc(B * n_cells * 4)
+    params = dr3.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
+
+    def step():
+        batch.build(1, B, True)
+        batch.detect(0, B, 3, 15, 20, 20.0, d_xy=d_pts)
+        batch.track(B, 0, d_pts, d_next, n_cells, d_st, d_err, params)
+
+    ctx.profile_enable(True)
+    step(); sync()
+    ctx.profile_reset()
+    el = timed_region(dist, step, sync, steps, 0)
+    ms_fast, n_fast = ctx.profile_read(dr3.PROF_FAST)
+    ms_lk, n_lk = ctx.profile_read(dr3.PROF_LK)
+    ctx.profile_enable(False)
+    pts = d_pts.download((B, n_cells, 2), np.float32)
+    st = d_st.download((B, n_cells), np.uint8)
+    have = pts[..., 0] != dr3.NO_POINT
+    out = {"frames_per_sec": aggregate_rate(dist, B * steps, el), "step_ms": el / steps * 1e3,
+           "cells_per_frame": int(n_cells), "features_per_frame": float(have.sum() / B),
+           "tracked_fraction_of_features": float(st[have].mean()) if have.any() else 0.0,
+           "detect_ms_per_batch": ms_fast / max(n_fast, 1), "lk_ms_per_batch": ms_lk / max(n_lk, 1),
+           "workload": "B = %d frames per step: LK pyramid + Scharr, half-sample pyramid (3 levels) + FAST-10 + grid-best "
+                       "Shi-Tomasi (cell 15), LK %dx%d / %d levels from the detected corners" % (B, WIN, WIN, MAX_LEVEL + 1)}
+    for d in (d_pts, d_next, d_st, d_err):
+        d.free()
+    return out
 
 
 def ref_bcast_leg(dist, ctx, dr3, batch, frames, levels, sync):
