@@ -203,3 +203,21 @@ def test_shi_tomasi_and_feather_helpers(O):
     assert canvas[1, 1, 0] == 5 and canvas[1, 1, 3] == 0.5 and canvas[0, 2, 3] == 0 and canvas[2, 0, 3] == 0
     out = O.normalize_canvas(canvas)
     assert out[1, 1, 0] == 10 and out[0, 2, 0] == 0
+
+
+def test_oracle_matches_numpy_restatement_on_the_reference_kitti_pair(O):
+    """the reference's own two-view input (tests/test_init.cpp:24-25, packed in tests/golden/kitti_pair.npz): the C oracle
+    and the independently laid-out numpy restatement agree bit for bit on real image statistics too"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_pair.npz"))
+    A, B = np.ascontiguousarray(z["kitti0"]), np.ascontiguousarray(z["kitti5"])
+    assert A.shape == (376, 1240)
+    assert np.array_equal(O.pyr_down(A), R.pyr_down(A)) and np.array_equal(O.scharr(A), R.scharr(A))
+    assert np.array_equal(O.halfsample(A, O.HALF_REF_SCALAR), R.halfsample_ref_scalar(A))
+    pyr = O.halfsample_pyramid(A, 3, O.HALF_REF_X86)
+    x, y, sc, lv = O.fast_detect_grid(pyr, 30, 20, 20.0)
+    pts = np.stack([x[lv >= 0], y[lv >= 0]], 1).astype(np.float32)[::12]            # ~30 corners keep the numpy loop short
+    po = O.lk_params(win=(21, 21), max_level=2, max_iters=30, eps=0.01)
+    o_xy, o_st, o_err, _ = O.lk_track(A, B, pts, None, po, order=O.ORDER_RASTER)
+    n_xy, n_st, n_err, _ = R.lk_track(A, B, pts, None, win=(21, 21), max_level=2, max_iters=30, eps=0.01)
+    assert np.array_equal(o_st, n_st) and np.array_equal(o_xy.view(np.uint32), np.asarray(n_xy, np.float32).view(np.uint32))
