@@ -270,6 +270,19 @@ def main(argv=None):
         g_st = d_st.download((B, N_PTS), np.uint8)[0]
         verified = bool(np.array_equal(g_xy, o_xy) and np.array_equal(g_st, o_st))
 
+    # ---- the reference's own call shape, PCIe included: one dr3hip_lk_track per pair with host buffers (2 frames up,
+    # pyramids + gradients + track, results down).  Reported beside `value`, never as `value` (inputs are not resident).
+    host_api = None
+    if dist.rank == 0:
+        n_host = 40
+        ctx.calcOpticalFlowPyrLK(frames[0], frames[1], pts, None, params)                    # warm-up (staging buffers)
+        t0 = time.perf_counter()
+        for i in range(n_host):
+            ctx.calcOpticalFlowPyrLK(frames[i % B], frames[i % B + 1], pts, None, params)
+        el_h = time.perf_counter() - t0
+        host_api = {"keypoints_per_sec": n_host * N_PTS / el_h, "ms_per_pair": el_h / n_host * 1e3,
+                    "sample": "%d calls of dr3hip_lk_track (host frames 1241x376 + %d points in, positions/status/err out)" % (n_host, N_PTS)}
+
     # ---- the whole front end on the device: pyramid + gradients, FAST detector, LK from the detected points -----
     frontend = None
     if not args.no_frontend:
@@ -342,6 +355,7 @@ def main(argv=None):
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "latency/issue-bound, not HBM-bound (SURVEY 8d): no roofline fraction claimed"},
+            "host_api_pcie_inclusive": host_api,
             "frontend": frontend,
             "warp": warp,
             "ref_pyramid_bcast": ref_bcast,
@@ -576,7 +590,18 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
         if time.perf_counter() - t0 > seconds or n_pairs >= 4096:
             break
     el = time.perf_counter() - t0
+    # the same call on ONE thread (SURVEY 8d asks for both), a quarter of the time budget
+    t1 = time.perf_counter()
+    n1 = 0
+    while True:
+        i = n1 % (len(frames) - 1)
+        O.lk_track(frames[i], frames[i + 1], pts, None, po, n_threads=1)
+        n1 += 1
+        if time.perf_counter() - t1 > max(2.0, seconds / 4) or n1 >= 1024:
+            break
+    el1 = time.perf_counter() - t1
     out = {"value": n_pairs * len(pts) / el, "unit": "keypoints/s", "cores": cores, "kind": "port",
+           "single_thread_value": n1 * len(pts) / el1, "single_thread_sample": "%d frame pairs, %.1f s" % (n1, el1),
            "cpu_model": cpu_model(),
            "sample": "%d frame pairs x %d points of the same stream, oracle dr3o_lk_track (pyramids + Scharr + "
                      "tracker per pair, OpenMP over rows/points), %.1f s" % (n_pairs, len(pts), el)}
