@@ -501,31 +501,42 @@ __global__ __launch_bounds__(256) void panorama_add_kernel(const PanoAddArgs a)
 // (int cast first, f32 divide, then narrowing to uchar), pixels with alpha_sum <= 0 stay 0.
 __global__ __launch_bounds__(256) void panorama_normalize_kernel(const PanoNormArgs a)
 {
-    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= a.cw || y >= a.ch) return;
-    const DR3_G f32x4* cp = reinterpret_cast<const DR3_G f32x4*>((gcu8)reinterpret_cast<const uint8_t*>(a.canvas) + (long long)y * a.cstride) + x;
-    uint32_t px[4];
+    // A wave owns 256 canvas pixels of one row.  Lane i reads pixels xw + 64 j + i (j = 0..3): four fully coalesced
+    // 1 KiB float4 loads; the finished [B G R 0] dwords are transposed through 1 KiB of LDS per wave (a wave's LDS
+    // operations complete in order, no barrier) so that lane i stores the 12 contiguous bytes of pixels 4 i .. 4 i + 3.
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][256];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int xw = blockIdx.x * 256;
+    const int y = blockIdx.y * 4 + wv;
+    if (xw >= a.cw || y >= a.ch) return;                                  // wave-uniform
+    const DR3_G f32x4* cp = reinterpret_cast<const DR3_G f32x4*>((gcu8)reinterpret_cast<const uint8_t*>(a.canvas) + (long long)y * a.cstride) + xw;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        px[i] = 0u;
-        if (x + i < a.cw) {
+    for (int j = 0; j < 4; ++j) {
+        const int i = 64 * j + lane;
+        uint32_t px = 0u;
+        if (xw + i < a.cw) {
             const f32x4 c4 = cp[i];
             if (c4.w > 0.0f) {
                 const uint32_t b = (uint32_t)(int)((float)(int)c4.x / c4.w) & 0xffu;
                 const uint32_t g = (uint32_t)(int)((float)(int)c4.y / c4.w) & 0xffu;
                 const uint32_t r = (uint32_t)(int)((float)(int)c4.z / c4.w) & 0xffu;
-                px[i] = b | (g << 8) | (r << 16);
+                px = b | (g << 8) | (r << 16);
             }
         }
+        lds[wv][i] = px;
     }
+    __builtin_amdgcn_wave_barrier();
+    const uint4 d = reinterpret_cast<const uint4*>(lds[wv])[lane];
+    const int x = xw + 4 * lane;
+    if (x >= a.cw) return;
     gu8 row = (gu8)a.out + (long long)y * a.ostride + (long long)x * 3;
     if (x + 3 < a.cw && ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.ostride) & 3) == 0) {
         DR3_G uint32_t* o = gcast<uint32_t>(row);
-        o[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);
-        o[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
-        o[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
+        o[0] = __builtin_amdgcn_perm(d.y, d.x, 0x04020100u);
+        o[1] = __builtin_amdgcn_perm(d.z, d.y, 0x05040201u);
+        o[2] = __builtin_amdgcn_perm(d.w, d.z, 0x06050402u);
     } else {
+        const uint32_t px[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (x + i < a.cw) { row[3 * i] = (uint8_t)px[i]; row[3 * i + 1] = (uint8_t)(px[i] >> 8); row[3 * i + 2] = (uint8_t)(px[i] >> 16); }
