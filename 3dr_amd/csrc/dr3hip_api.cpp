@@ -40,6 +40,8 @@ struct dr3hip_batch {
     dr3hip_ctx* ctx = nullptr;
     int w = 0, h = 0, win_w = 0, win_h = 0, levels = 0, capacity = 0;
     LevelDev lv[DR3HIP_MAX_LEVELS];
+    void* img_base[DR3HIP_MAX_LEVELS] = {nullptr};   // allocation starts (lv[].img / .der point at the interior origin)
+    void* der_base[DR3HIP_MAX_LEVELS] = {nullptr};
     size_t bytes = 0;
     // detector storage (dr3hip_batch_detect), allocated on first use: half-sample pyramid levels 1.. of every
     // slot (continuous rows like the reference's cv::Mat levels), one score map and one cell-key array per slot
@@ -689,14 +691,14 @@ long long dr3hip_batch_bcast_slot(dr3hip_batch* b, int slot, int root, int with_
     NCCLCHK(ctx, g_rccl.GroupStart());
     for (int l = 0; l < b->levels; ++l) {
         const LevelDev& v = b->lv[l];
-        // whole rows including the pitch slack: the receiver's plane becomes byte-identical to the root's
-        uint8_t* pi = v.img + (size_t)v.step * slot;
-        const size_t ib = (size_t)v.pitch * v.h;
+        // whole rows including the pitch slack and the physical border: the receiver's plane becomes byte-identical
+        uint8_t* pi = v.img + (size_t)v.step * slot - ((size_t)v.pad_y * v.pitch + v.pad_x);
+        const size_t ib = (size_t)v.pitch * (v.h + 2 * v.pad_y);
         int r = g_rccl.Broadcast(pi, pi, ib, kNcclUint8, root, ctx->comm, ctx->stream);
         moved += (long long)ib;
         if (r == 0 && with_deriv) {
-            uint8_t* pd = (uint8_t*)v.der + (size_t)v.dstep * slot;
-            const size_t db = (size_t)v.dpitch * v.h;
+            uint8_t* pd = (uint8_t*)v.der + (size_t)v.dstep * slot - ((size_t)v.pad_y * v.dpitch + (size_t)4 * v.pad_x);
+            const size_t db = (size_t)v.dpitch * (v.h + 2 * v.pad_y);
             r = g_rccl.Broadcast(pd, pd, db, kNcclUint8, root, ctx->comm, ctx->stream);
             moved += (long long)db;
         }
@@ -782,10 +784,15 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
     for (int l = 0; l <= L; ++l) {
         LevelDev& v = b->lv[l];
         v.w = lw; v.h = lh;
-        v.pitch = align_up(lw + 8, 64);
-        v.dpitch = align_up(4 * lw + 16, 128);
-        v.step = (long long)align_up(v.pitch * lh, 256);
-        v.dstep = (long long)align_up(v.dpitch * lh, 256);
+        // levels >= 1 carry OpenCV's winSize border physically (lk_kernels.hip): wide enough for the template window,
+        // the staged search region (window + 4 px margin) and their dword alignment slop
+        v.pad_x = l ? align_up(win_w + 16, 4) : 0;
+        v.pad_y = l ? win_h + 6 : 0;
+        v.pitch = align_up(lw + 2 * v.pad_x + 8, 64);
+        v.dpitch = align_up(4 * (lw + 2 * v.pad_x) + 16, 128);
+        const int rows = lh + 2 * v.pad_y;
+        v.step = (long long)align_up(v.pitch * rows, 256);
+        v.dstep = (long long)align_up(v.dpitch * rows, 256);
         const size_t ib = (size_t)v.step * capacity + 256, db = (size_t)v.dstep * capacity + 256;
         void *pi = nullptr, *pd = nullptr;
         if (hipMalloc(&pi, ib) != hipSuccess || hipMalloc(&pd, db) != hipSuccess) {
@@ -794,8 +801,10 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
             dr3hip_batch_destroy(b);
             return fail(ctx, DR3HIP_ENOMEM, "batch_create: hipMalloc failed at level %d (%zu + %zu bytes)", l, ib, db);
         }
-        v.img = (uint8_t*)pi; v.der = (int16_t*)pd;
-        // pitch slack is read (never used) by aligned over-reads: keep it defined
+        b->img_base[l] = pi; b->der_base[l] = pd;
+        // img / der address the interior origin; pitch slack and borders are read by aligned over-reads: keep them defined
+        v.img = (uint8_t*)pi + (size_t)v.pad_y * v.pitch + v.pad_x;
+        v.der = (int16_t*)((uint8_t*)pd + (size_t)v.pad_y * v.dpitch + (size_t)4 * v.pad_x);
         (void)hipMemsetAsync(pi, 0, ib, ctx->stream);
         (void)hipMemsetAsync(pd, 0, db, ctx->stream);
         b->bytes += ib + db;
@@ -812,8 +821,8 @@ void dr3hip_batch_destroy(dr3hip_batch* b)
     DeviceGuard g(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     for (int l = 0; l < DR3HIP_MAX_LEVELS; ++l) {
-        if (b->lv[l].img) (void)hipFree(b->lv[l].img);
-        if (b->lv[l].der) (void)hipFree(b->lv[l].der);
+        if (b->img_base[l]) (void)hipFree(b->img_base[l]);
+        if (b->der_base[l]) (void)hipFree(b->der_base[l]);
         if (b->det.hs[l]) (void)hipFree(b->det.hs[l]);
     }
     if (b->det.score) (void)hipFree(b->det.score);
@@ -885,6 +894,7 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             ProfEvent p0; prof_begin(ctx, l == 0 ? DR3HIP_PROF_PYR_L0 : -1, p0);
             HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream));
             prof_end(ctx, p0);
+            if (down) HIPCHK(ctx, launch_pad_reflect(b->lv[l + 1], first + s0, n, ctx->stream));   // level l + 1 is complete: its border
         }
     }
     prof_end(ctx, pe);

@@ -20,6 +20,8 @@ struct LevelDev {
     int dpitch;            // bytes per derivative row (>= 4*w, multiple of 128)
     long long step;        // bytes between slots (image)
     long long dstep;       // bytes between slots (derivative)
+    int pad_x, pad_y;      // physical border around the plane (levels >= 1): REFLECT_101 pixels / zero derivatives, so the
+                           // tracker never leaves the fast path there; img / der point at the interior origin.  0 = none
 };
 
 struct PyrArgs {
@@ -127,6 +129,7 @@ struct HalfArgs {
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
+hipError_t launch_pad_reflect(const LevelDev& lv, int first, int n_slots, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);

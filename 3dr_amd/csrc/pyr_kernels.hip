@@ -174,7 +174,33 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
     }
 }
 
+// REFLECT_101 border of a padded level (levels >= 1 of a batch): OpenCV pads every pyramid level by winSize
+// (SURVEY A-1); doing the same physically for the small levels -- where a third of the windows cross the image edge --
+// keeps the tracker on its fast path there.  One lane per dword of the padded plane; interior dwords are skipped, so
+// reads touch the interior only and writes the border only.  The derivative border is zero from allocation on.
+__global__ __launch_bounds__(256) void pad_reflect_kernel(const LevelDev lv, int first)
+{
+    const int xq = (blockIdx.x * 64 + threadIdx.x) * 4 - lv.pad_x;      // first column of this dword (pad_x % 4 == 0)
+    const int y = blockIdx.y * 4 + threadIdx.y - lv.pad_y;
+    if (xq >= lv.w + lv.pad_x || y >= lv.h + lv.pad_y) return;
+    if (y >= 0 && y < lv.h && xq >= 0 && xq + 3 < lv.w) return;          // interior dword
+    uint8_t* img = lv.img + (long long)(first + blockIdx.z) * lv.step;
+    const uint8_t* srow = img + (long long)reflect101(y, lv.h) * lv.pitch;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, lv.w)] << (8 * k);
+    *reinterpret_cast<uint32_t*>(img + (long long)y * lv.pitch + xq) = v;
+}
+
 }  // namespace
+
+hipError_t launch_pad_reflect(const LevelDev& lv, int first, int n_slots, hipStream_t s)
+{
+    if (n_slots <= 0 || lv.pad_x <= 0) return hipSuccess;
+    dim3 block(64, 4), grid((lv.w + 2 * lv.pad_x + 255) / 256, (lv.h + 2 * lv.pad_y + 3) / 4, n_slots);
+    hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, lv, first);
+    return hipGetLastError();
+}
 
 hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool deriv, bool level0, hipStream_t s)
 {

