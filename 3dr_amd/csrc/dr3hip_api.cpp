@@ -894,9 +894,11 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             ProfEvent p0; prof_begin(ctx, l == 0 ? DR3HIP_PROF_PYR_L0 : -1, p0);
             HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream));
             prof_end(ctx, p0);
-            if (down) HIPCHK(ctx, launch_pad_reflect(b->lv[l + 1], first + s0, n, ctx->stream));   // level l + 1 is complete: its border
         }
     }
+    // the physical REFLECT_101 border of levels 1 .. L (read by the tracker only, never by the pyramid kernels): one launch
+    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768)
+        HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

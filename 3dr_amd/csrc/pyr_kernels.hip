@@ -176,15 +176,34 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
 
 // REFLECT_101 border of a padded level (levels >= 1 of a batch): OpenCV pads every pyramid level by winSize
 // (SURVEY A-1); doing the same physically for the small levels -- where a third of the windows cross the image edge --
-// keeps the tracker on its fast path there.  One lane per dword of the padded plane; interior dwords are skipped, so
-// reads touch the interior only and writes the border only.  The derivative border is zero from allocation on.
-__global__ __launch_bounds__(256) void pad_reflect_kernel(const LevelDev lv, int first)
+// keeps the tracker on its fast path there.  One lane per border dword; reads touch the interior only, writes the border
+// (the mixed dword at the right edge rewrites its interior bytes with themselves).  The derivative border is zero from
+// allocation on.
+__global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
 {
-    const int xq = (blockIdx.x * 64 + threadIdx.x) * 4 - lv.pad_x;      // first column of this dword (pad_x % 4 == 0)
-    const int y = blockIdx.y * 4 + threadIdx.y - lv.pad_y;
-    if (xq >= lv.w + lv.pad_x || y >= lv.h + lv.pad_y) return;
-    if (y >= 0 && y < lv.h && xq >= 0 && xq + 3 < lv.w) return;          // interior dword
-    uint8_t* img = lv.img + (long long)(first + blockIdx.z) * lv.step;
+    const LevelDev& lv = a.lv[blockIdx.z];                                // grid z = level (1 .. L), y = slot
+    const int first = a.first;
+    // flattened index over the border dwords only: first the 2 pad_y full-width rows above and below, then for every
+    // interior row the pad_x / 4 dwords on the left and the dwords from the last interior one to the right edge
+    const int wq = (lv.w + 2 * lv.pad_x + 3) / 4;                        // dwords per padded row
+    const int lq = lv.pad_x / 4;                                          // left border dwords of an interior row
+    const int r0 = lv.w / 4;                                              // first dword (interior numbering) that is not purely interior
+    const int rq = (lv.w + lv.pad_x + 3) / 4 - r0;                        // right border dwords (incl. the mixed one)
+    const int n_band = 2 * lv.pad_y * wq, n_side = lv.h * (lq + rq);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_band + n_side) return;
+    int xq, y;
+    if (i < n_band) {
+        const int r = i / wq;
+        y = r < lv.pad_y ? r - lv.pad_y : lv.h + (r - lv.pad_y);
+        xq = (i - r * wq) * 4 - lv.pad_x;
+    } else {
+        const int j = i - n_band;
+        y = j / (lq + rq);
+        const int c = j - y * (lq + rq);
+        xq = c < lq ? c * 4 - lv.pad_x : (r0 + (c - lq)) * 4;
+    }
+    uint8_t* img = lv.img + (long long)(first + blockIdx.y) * lv.step;
     const uint8_t* srow = img + (long long)reflect101(y, lv.h) * lv.pitch;
     uint32_t v = 0;
 #pragma unroll
@@ -194,11 +213,19 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const LevelDev lv, int
 
 }  // namespace
 
-hipError_t launch_pad_reflect(const LevelDev& lv, int first, int n_slots, hipStream_t s)
+hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int first, int n_slots, hipStream_t s)
 {
-    if (n_slots <= 0 || lv.pad_x <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((lv.w + 2 * lv.pad_x + 255) / 256, (lv.h + 2 * lv.pad_y + 3) / 4, n_slots);
-    hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, lv, first);
+    if (n_slots <= 0 || n_lv <= 0) return hipSuccess;
+    PadArgs a; a.first = first; a.n_lv = n_lv;
+    int n_max = 0;
+    for (int i = 0; i < n_lv; ++i) {
+        a.lv[i] = lv[i];
+        const int wq = (lv[i].w + 2 * lv[i].pad_x + 3) / 4, lq = lv[i].pad_x / 4, rq = (lv[i].w + lv[i].pad_x + 3) / 4 - lv[i].w / 4;
+        const int n = 2 * lv[i].pad_y * wq + lv[i].h * (lq + rq);
+        if (n > n_max) n_max = n;
+    }
+    dim3 block(256), grid((n_max + 255) / 256, n_slots, n_lv);           // one launch for every padded level
+    hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
 
