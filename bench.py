@@ -291,6 +291,22 @@ def main(argv=None):
         g_st = d_st.download((B, N_PTS), np.uint8)[0]
         verified = bool(np.array_equal(g_xy, o_xy) and np.array_equal(g_st, o_st))
 
+    # ---- what this box's HBM delivers on a plain device-to-device copy (report beside the nominal 8 TB/s)
+    copy_gbps = None
+    if dist.rank == 0:
+        try:
+            a_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % ctx.device); b_t = torch.empty_like(a_t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b_t.copy_(a_t); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                b_t.copy_(a_t)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbps = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9          # bytes read + bytes written
+            del a_t, b_t
+        except Exception:                                        # noqa: BLE001 -- informational only
+            copy_gbps = None
+
     # ---- the reference's own call shape, PCIe included: one dr3hip_lk_track per pair with host buffers (2 frames up,
     # pyramids + gradients + track, results down).  Reported beside `value`, never as `value` (inputs are not resident).
     host_api = None
@@ -377,6 +393,7 @@ def main(argv=None):
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "VALU-issue bound, not HBM-bound (SURVEY 8d): no HBM fraction claimed",
                           "valu_issue": lk_valu_issue(lk_ms, B * N_PTS)},
+            "hbm_copy_measured_GBps": copy_gbps,
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,
             "warp": warp,
@@ -627,6 +644,19 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
            "cpu_model": cpu_model(),
            "sample": "%d frame pairs x %d points of the same stream, oracle dr3o_lk_track (pyramids + Scharr + "
                      "tracker per pair, OpenMP over rows/points), %.1f s" % (n_pairs, len(pts), el)}
+    try:                                                 # the real thing, where a cv2 module happens to exist (it does not in this image)
+        import cv2
+        crit = (cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, MAX_ITERS, EPS)
+        p0 = pts.reshape(-1, 1, 2).astype(np.float32)
+        t2 = time.perf_counter(); n2 = 0
+        while time.perf_counter() - t2 < max(2.0, seconds / 4) and n2 < 1024:
+            i = n2 % (len(frames) - 1)
+            cv2.calcOpticalFlowPyrLK(frames[i], frames[i + 1], p0, None, winSize=(WIN, WIN), maxLevel=MAX_LEVEL, criteria=crit)
+            n2 += 1
+        out["opencv"] = {"version": cv2.__version__, "keypoints_per_sec": n2 * len(pts) / (time.perf_counter() - t2),
+                         "threads": cv2.getNumThreads(), "note": "cv2.calcOpticalFlowPyrLK on the same pairs"}
+    except ImportError:
+        out["opencv"] = None
     if with_warp:
         tile = cheap_tile(synth, 4000, 3000)
         M = synth.tile_homography(0, 4000, 3000)

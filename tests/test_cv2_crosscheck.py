@@ -1,0 +1,52 @@
+"""Optional pin of the oracle against a real OpenCV ("skip-if-missing cv2 cross-check").  Neither this image nor
+the GPU box ships cv2, so these tests are skipped there; wherever an OpenCV 3.x/4.x Python module exists they compare the
+oracle's restatement of the OpenCV calls the reference makes with OpenCV itself, on the reference's own KITTI pair."""
+import os
+
+import numpy as np
+import pytest
+
+cv2 = pytest.importorskip("cv2")
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_pair.npz")
+
+
+@pytest.fixture(scope="module")
+def kitti():
+    z = np.load(FIX)
+    return np.ascontiguousarray(z["kitti0"]), np.ascontiguousarray(z["kitti5"])
+
+
+def test_pyrdown_and_scharr_match_opencv(O, kitti):
+    A, _ = kitti
+    assert np.array_equal(O.pyr_down(A), cv2.pyrDown(A))
+    d = O.scharr(A).astype(np.int32)
+    gx = cv2.Scharr(A, cv2.CV_16S, 1, 0).astype(np.int32); gy = cv2.Scharr(A, cv2.CV_16S, 0, 1).astype(np.int32)
+    assert np.array_equal(d[..., 0], gx) and np.array_equal(d[..., 1], gy)
+
+
+def test_lk_matches_opencv_within_tolerance(O, kitti):
+    A, B = kitti
+    pyr = O.halfsample_pyramid(A, 3, O.HALF_REF_X86)
+    x, y, sc, lv = O.fast_detect_grid(pyr, 30, 20, 20.0)
+    pts = np.stack([x[lv >= 0], y[lv >= 0]], 1).astype(np.float32)
+    crit = (cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, 30, 0.01)
+    c_xy, c_st, c_err = cv2.calcOpticalFlowPyrLK(A, B, pts.reshape(-1, 1, 2), None, winSize=(21, 21), maxLevel=2, criteria=crit)
+    o_xy, o_st, o_err, _ = O.lk_track(A, B, pts, None, O.lk_params(win=(21, 21), max_level=2, max_iters=30, eps=0.01), order=O.ORDER_RASTER)
+    c_xy = c_xy.reshape(-1, 2); c_st = c_st.reshape(-1)
+    assert (c_st == o_st).mean() > 0.99
+    both = (c_st == 1) & (o_st == 1)
+    d = np.abs(c_xy - o_xy).max(1)[both]
+    assert (d <= 1e-3).mean() > 0.97          # OpenCV's SIMD summation order differs from the scalar order restated here
+
+
+def test_warp_perspective_matches_opencv(O, kitti, synth):
+    A, B = kitti
+    bgr = np.stack([A, B, A], -1)
+    M = synth.tile_homography(3, 1240, 376)
+    want = cv2.warpPerspective(bgr, M, (1400, 480), flags=cv2.INTER_LINEAR)
+    assert np.array_equal(O.warp_perspective(bgr, M, (1400, 480)), want)
+    f = bgr.astype(np.float32)
+    f4 = np.dstack([f, np.ones(f.shape[:2], np.float32)])
+    got = O.warp_perspective(f4, M, (1400, 480)); ref = cv2.warpPerspective(f4, M, (1400, 480), flags=cv2.INTER_LINEAR)
+    assert np.abs(got - ref).max() <= np.spacing(np.float32(255.0))          # 1 ULP (north_star)
