@@ -29,7 +29,7 @@ WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
-PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST = 0, 1, 2, 3, 4, 5, 6, 7, 8
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 COMM_ID_BYTES = 128
 WARP_SPHERICAL, WARP_CYLINDRICAL = 1, 2
 NO_POINT = np.float32(-1.0e6)
@@ -118,6 +118,9 @@ def _signatures():
         "dr3hip_check_fundamental": ([vp, vp, ip, vp, vp, ip, C.c_float, vp, vp], ip),
         "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_warp_local_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
+        "dr3hip_stitch_geometry": ([vp, ip, ip, vp, vp, vp, P(ip), P(ip)], ip),
+        "dr3hip_stitch_compose": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
+        "dr3hip_stitch_compose_dev": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
         "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
@@ -283,6 +286,18 @@ class Context:
         self._chk(lib().dr3hip_check_fundamental(self.h, _p(F), len(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(scores),
                                                  None if inl is None else _p(inl)))
         return scores, inl
+
+    def stitch_compose(self, left, right, H, alpha=0.5, beta=0.5, gamma=0.0):
+        """Stitch::process after align_pair (src/stitch.cpp:33-80): geometry on the host, both warps and the addWeighted
+        blend in one kernel; returns the stitched 8UC3 image"""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        Hinv, T, M, (nw, nh) = stitch_geometry(H, right.shape[1], right.shape[0])
+        out = np.zeros((nh, nw, 3), np.uint8)
+        self._chk(lib().dr3hip_stitch_compose(self.h, _p(left), left.shape[1], left.shape[0], left.strides[0],
+                                              _p(right), right.shape[1], right.shape[0], right.strides[0],
+                                              _p(np.ascontiguousarray(T.reshape(9))), _p(np.ascontiguousarray(M.reshape(9))), nw, nh,
+                                              C.c_float(alpha), C.c_float(beta), C.c_float(gamma), _p(out), out.strides[0]))
+        return out
 
     def warp_spherical(self, img, f):
         """utils::warp_spherical (src/utils.cpp:196-201): map generation fused with the remap"""
@@ -533,3 +548,14 @@ def panorama_ramp(min_x, max_x, feathering_width):
     if n < 0:
         raise Dr3HipError("dr3hip_panorama_ramp: the reference throws for this box (%d)" % n)
     return ramp[:n]
+
+
+def stitch_geometry(H, w, h):
+    """Stitch::process geometry (src/stitch.cpp:33-71), host-only -> (Hinv, T, M_right, (new_w, new_h))"""
+    H = np.ascontiguousarray(H, np.float32).reshape(9)
+    Hinv, T, M = (np.zeros(9, np.float32) for _ in range(3))
+    nw, nh = C.c_int(), C.c_int()
+    rc = lib().dr3hip_stitch_geometry(_p(H), int(w), int(h), _p(Hinv), _p(T), _p(M), C.byref(nw), C.byref(nh))
+    if rc != 0:
+        raise Dr3HipError("dr3hip_stitch_geometry: singular homography (%d)" % rc)
+    return Hinv.reshape(3, 3), T.reshape(3, 3), M.reshape(3, 3), (nw.value, nh.value)

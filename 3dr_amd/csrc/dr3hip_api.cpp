@@ -592,6 +592,96 @@ int dr3hip_panorama_normalize(dr3hip_ctx* ctx, const float* d_canvas, int cw, in
     return DR3HIP_OK;
 }
 
+// ---- stitch compose (src/stitch.cpp:33-80) -------------------------------------------------------------------------
+static void gemm33_f32(const float A[9], const float B[9], float C[9])   // CV_32F gemm: double accumulation, one rounding
+{
+    float t[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += (double)A[3 * i + k] * (double)B[3 * k + j];
+            t[3 * i + j] = (float)acc;
+        }
+    memcpy(C, t, sizeof(t));
+}
+
+int dr3hip_stitch_geometry(const float H[9], int w, int h, float Hinv[9], float T[9], float M_right[9], int* new_w, int* new_h)
+{
+    if (!H || !Hinv || !T || !M_right || !new_w || !new_h || w < 1 || h < 1) return DR3HIP_EINVAL;
+    // cv::Mat::inv() on a CV_32F 3x3 (:34): determinant and cofactors in double, stored as float
+    const double d0 = (double)H[0] * ((double)H[4] * H[8] - (double)H[5] * H[7]) - (double)H[1] * ((double)H[3] * H[8] - (double)H[5] * H[6]) +
+                      (double)H[2] * ((double)H[3] * H[7] - (double)H[4] * H[6]);
+    if (d0 == 0.0) return DR3HIP_EINVAL;
+    const double d = 1.0 / d0;
+    float inv[9];
+    inv[0] = (float)(((double)H[4] * H[8] - (double)H[5] * H[7]) * d); inv[1] = (float)(((double)H[2] * H[7] - (double)H[1] * H[8]) * d);
+    inv[2] = (float)(((double)H[1] * H[5] - (double)H[2] * H[4]) * d); inv[3] = (float)(((double)H[5] * H[6] - (double)H[3] * H[8]) * d);
+    inv[4] = (float)(((double)H[0] * H[8] - (double)H[2] * H[6]) * d); inv[5] = (float)(((double)H[2] * H[3] - (double)H[0] * H[5]) * d);
+    inv[6] = (float)(((double)H[3] * H[7] - (double)H[4] * H[6]) * d); inv[7] = (float)(((double)H[1] * H[6] - (double)H[0] * H[7]) * d);
+    inv[8] = (float)(((double)H[0] * H[4] - (double)H[1] * H[3]) * d);
+    const float scale = (float)(1.0 / (double)inv[8]);                  // Hinv * (1.0 / Hinv.at<float>(2, 2))  (:35)
+    for (int i = 0; i < 9; ++i) Hinv[i] = inv[i] * scale;
+    const float cx[4] = {0.f, (float)w, 0.f, (float)w}, cy[4] = {0.f, 0.f, (float)h, (float)h};
+    float X[8], Y[8];
+    for (int i = 0; i < 4; ++i) {                                       // :39-60
+        float t[3];
+        for (int r = 0; r < 3; ++r)
+            t[r] = (float)((double)Hinv[3 * r] * (double)cx[i] + (double)Hinv[3 * r + 1] * (double)cy[i] + (double)Hinv[3 * r + 2] * 1.0);
+        X[i] = t[0] / t[2]; Y[i] = t[1] / t[2];
+        X[4 + i] = cx[i]; Y[4 + i] = cy[i];
+    }
+    const float mnx = *std::min_element(X, X + 8), mny = *std::min_element(Y, Y + 8);
+    const float mxx = *std::max_element(X, X + 8), mxy = *std::max_element(Y, Y + 8);
+    *new_w = (int)(std::ceil(mxx) - std::floor(mnx));                   // :67-68
+    *new_h = (int)(std::ceil(mxy) - std::floor(mny));
+    T[0] = 1.f; T[1] = 0.f; T[2] = -mnx; T[3] = 0.f; T[4] = 1.f; T[5] = -mny; T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;   // :70-71
+    gemm33_f32(T, Hinv, M_right);                                       // translate_top_left_mat * Hinv (:73)
+    return DR3HIP_OK;
+}
+
+int dr3hip_stitch_compose_dev(dr3hip_ctx* ctx, const uint8_t* d_left, int lw, int lh, int lstride,
+                              const uint8_t* d_right, int rw, int rh, int rstride,
+                              const float T[9], const float M_right[9], int new_w, int new_h,
+                              float alpha, float beta, float gamma, uint8_t* d_out, int ostride)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_left || !d_right || !T || !M_right || !d_out || lw < 1 || lh < 1 || rw < 1 || rh < 1 || new_w < 1 || new_h < 1 ||
+        lstride < 3 * lw || rstride < 3 * rw || ostride < 3 * new_w)
+        return fail(ctx, DR3HIP_EINVAL, "stitch_compose: bad arguments");
+    DeviceGuard g(ctx->device);
+    StitchArgs a;
+    make_job(a.job[0], d_left, lw, lh, lstride, d_out, new_w, new_h, ostride, T, 0);           // :74
+    make_job(a.job[1], d_right, rw, rh, rstride, d_out, new_w, new_h, ostride, M_right, 0);    // :73
+    a.dst = d_out; a.dw = new_w; a.dh = new_h; a.dstride = ostride;
+    a.alpha = alpha; a.beta = beta; a.gamma = gamma;
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_STITCH, pe);
+    HIPCHK(ctx, launch_stitch_compose(a, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
+}
+
+int dr3hip_stitch_compose(dr3hip_ctx* ctx, const uint8_t* left, int lw, int lh, int lstride,
+                          const uint8_t* right, int rw, int rh, int rstride,
+                          const float T[9], const float M_right[9], int new_w, int new_h,
+                          float alpha, float beta, float gamma, uint8_t* out, int ostride)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!left || !right || !out || lw < 1 || lh < 1 || rw < 1 || rh < 1 || new_w < 1 || new_h < 1 ||
+        lstride < 3 * lw || rstride < 3 * rw || ostride < 3 * new_w)
+        return fail(ctx, DR3HIP_EINVAL, "stitch_compose: bad arguments");
+    DeviceGuard g(ctx->device);
+    const int lp = align_up(3 * lw, 64), rp = align_up(3 * rw, 64), op = align_up(3 * new_w, 64);
+    int rc;
+    if ((rc = stage_reserve(ctx, 0, (size_t)lp * lh)) || (rc = stage_reserve(ctx, 2, (size_t)rp * rh)) || (rc = stage_reserve(ctx, 1, (size_t)op * new_h))) return rc;
+    if ((rc = copy2d_h2d(ctx, ctx->stage[0].p, lp, left, lstride, (size_t)3 * lw, lh))) return rc;
+    if ((rc = copy2d_h2d(ctx, ctx->stage[2].p, rp, right, rstride, (size_t)3 * rw, rh))) return rc;
+    if ((rc = dr3hip_stitch_compose_dev(ctx, (const uint8_t*)ctx->stage[0].p, lw, lh, lp, (const uint8_t*)ctx->stage[2].p, rw, rh, rp,
+                                        T, M_right, new_w, new_h, alpha, beta, gamma, (uint8_t*)ctx->stage[1].p, op))) return rc;
+    if ((rc = copy2d_d2h(ctx, out, ostride, ctx->stage[1].p, op, (size_t)3 * new_w, new_h))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
 // ---- multi-GPU: RCCL broadcast --------------------------------------------------------------
 // librccl is resolved with dlopen on first use: libdr3hip.so has no link-time dependency on it, and a
 // process that already carries an RCCL (PyTorch bundles one under the same SONAME) shares that copy.

@@ -69,6 +69,12 @@ struct WarpJobDev {
     int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191)
 };
 
+struct StitchArgs {        // fused Stitch compose (src/stitch.cpp:72-80): job[0] = left (M = T), job[1] = right (M = T * Hinv)
+    WarpJobDev job[2];     // .dst / .dw / .dh / .dstride of the jobs are the output canvas (same for both)
+    uint8_t* dst; int dw, dh, dstride;
+    float alpha, beta, gamma;
+};
+
 struct PanoAddArgs {       // fused Panorama::add_img_to_canvas (src/panorama.cpp:178-212)
     const uint8_t* img; int w, h, istride;        // 8UC3 source image
     float* canvas;      int cw, ch, cstride;      // 32FC4 weighted canvas (read-modify-write)
@@ -143,6 +149,7 @@ hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
+hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 

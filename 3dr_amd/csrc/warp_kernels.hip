@@ -438,6 +438,61 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
     else             single_px<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dstride, x, y, t[0]);
 }
 
+// ---- fused stitch compose ------------------------------------------------------------------------------------------
+// reconstruct::Stitch::process after align_pair, reference src/stitch.cpp:72-80: warpPerspective(right, T * Hinv),
+// warpPerspective(left, T), addWeighted(left, alpha, right, beta, gamma) -- three full-canvas passes (3 r + 3 w, 3 r + 3 w,
+// 6 r + 3 w bytes per pixel) as one: a lane owns 4 adjacent output pixels, samples both sources with the 8UC3 machinery
+// above (each with its own job record: inverse map, block split, fast-coordinate flag) and blends
+// saturate(cvRound(l * alpha + r * beta + gamma)) in f32 as cv::addWeighted does for 8-bit data.
+__device__ __forceinline__ uint32_t add_weighted_u8(uint32_t l, uint32_t r, float alpha, float beta, float gamma)
+{
+    const float t = (float)l * alpha + (float)r * beta + gamma;
+    const int v = __float2int_rn(t);
+    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(256) void stitch_compose_kernel(const StitchArgs a)
+{
+    using WT = WaveTile<4>;
+    const int x = (blockIdx.x * WT::LX + (threadIdx.x & (WT::LX - 1))) * 4;
+    const int y = (blockIdx.y * 4 + threadIdx.y) * WT::LY + (threadIdx.x >> WT::LOG_LX);
+    if (x >= a.dw || y >= a.dh) return;
+    uint32_t acc[2][3][4];                               // [source][channel][pixel] accumulators, result in byte 2
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const WarpJobDev& jb = a.job[s];
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
+        Tap t[4];
+        persp_taps<4, GENERIC>(M, jb.bw0, jb.bw0_shift, jb.fast != 0, x, y, t);
+        gcu8 src = (gcu8)jb.src;
+        const bool src_aligned = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)jb.sstride) & 3) == 0 &&
+                                 jb.sstride < (1 << 24) && jb.sh < (1 << 24) && (long long)jb.sstride * jb.sh < (1LL << 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[s][0][i] = acc[s][1][i] = acc[s][2][i] = 0u;
+            if (x + i < a.dw) pixel_8uc3(src, jb.sw, jb.sh, jb.sstride, src_aligned, t[i], acc[s][0][i], acc[s][1][i], acc[s][2][i]);
+        }
+    }
+    uint32_t o[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[3 * i + c] = add_weighted_u8(byte2(acc[0][c][i]), byte2(acc[1][c][i]), a.alpha, a.beta, a.gamma);
+    gu8 row = (gu8)a.dst + (long long)y * a.dstride + (long long)x * 3;
+    if (x + 3 < a.dw && ((reinterpret_cast<uintptr_t>(a.dst) | (uintptr_t)a.dstride) & 3) == 0) {
+        DR3_G uint32_t* q = gcast<uint32_t>(row);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = o[4 * d] | (o[4 * d + 1] << 8) | (o[4 * d + 2] << 16) | (o[4 * d + 3] << 24);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x + i < a.dw) { row[3 * i] = (uint8_t)o[3 * i]; row[3 * i + 1] = (uint8_t)o[3 * i + 1]; row[3 * i + 2] = (uint8_t)o[3 * i + 2]; }
+    }
+}
+
 // ---- fused panorama paste -----------------------------------------------------------------
 // reconstruct::Panorama::add_img_to_canvas, reference src/panorama.cpp:178-212, in one pass over the
 // bounding-box columns of the canvas: the reference builds a (B,G,R,1) 32FC4 copy of the image, warps it
@@ -646,6 +701,17 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
     default: return hipErrorInvalidValue;
     }
 #undef DR3_REMAP_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s)
+{
+    if (a.dw <= 0 || a.dh <= 0) return hipSuccess;
+    dim3 block(64, 4);
+    const int tw = WaveTile<4>::LX * 4, th = 4 * WaveTile<4>::LY;
+    dim3 grid((a.dw + tw - 1) / tw, (a.dh + th - 1) / th, 1);
+    if (a.job[0].bw0_shift < 0 || a.job[1].bw0_shift < 0) hipLaunchKernelGGL(stitch_compose_kernel<true>,  grid, block, 0, s, a);
+    else                                                   hipLaunchKernelGGL(stitch_compose_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -522,7 +522,40 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
             d.free()
     res["workload"] = "configs[2]: 8 tiles 4000x3000, per-pixel homography, bilinear, border 0"
     res["paste"] = paste_leg(dist, ctx, dr3, synth, sync, tile, steps)
+    res["stitch"] = stitch_leg(dist, ctx, dr3, synth, sync, tile, steps)
     return res
+
+
+def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
+    """reconstruct::Stitch::process after align_pair (src/stitch.cpp:33-80) on one 4000x3000 pair: geometry on the host, both
+    8UC3 warps and the addWeighted blend as ONE kernel (the reference: two full-canvas warps + one blend pass)."""
+    TH_, TW_ = tile.shape[:2]
+    a = np.deg2rad(1.5)
+    H = np.array([[np.cos(a), -np.sin(a), -0.45 * TW_], [np.sin(a), np.cos(a), 35.0], [1e-5, -6e-6, 1.0]], np.float32)
+    Hinv, T, M, (nw, nh) = dr3.stitch_geometry(H, TW_, TH_)
+    op = (3 * nw + 255) // 256 * 256
+    d_l, d_r, d_o = ctx.to_device(tile), ctx.to_device(np.roll(tile, -int(0.45 * TW_), axis=1)), ctx.alloc(op * nh)
+    Tc, Mc = np.ascontiguousarray(T.reshape(9)), np.ascontiguousarray(M.reshape(9))
+    L = dr3.lib()
+
+    def step():
+        ctx._chk(L.dr3hip_stitch_compose_dev(ctx.h, d_l.ptr, TW_, TH_, 3 * TW_, d_r.ptr, TW_, TH_, 3 * TW_, Tc.ctypes.data, Mc.ctypes.data,
+                                             nw, nh, 0.5, 0.5, 0.0, d_o.ptr, op))
+
+    ctx.profile_enable(True)
+    step(); sync()
+    ctx.profile_reset()
+    el = timed_region(dist, step, sync, steps, 0)
+    ms, n = ctx.profile_read(dr3.PROF_STITCH)
+    ctx.profile_enable(False)
+    for d in (d_l, d_r, d_o):
+        d.free()
+    k_ms = ms / max(n, 1)
+    alg = 2 * TW_ * TH_ * 3 + nw * nh * 3                 # both sources read once + the canvas written once
+    return {"canvas": [nw, nh], "kernel_ms": k_ms, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
+            "roofline": {"kernel": "stitch_compose_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
+            "replaces": "reference passes: warp right (3 r + 3 w per canvas px), warp left (3 r + 3 w), addWeighted (6 r + 3 w)"}
 
 
 def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):

@@ -244,6 +244,24 @@ int dr3hip_warp_local(dr3hip_ctx* ctx, const void* src, int w, int h, int sstrid
 int dr3hip_warp_local_dev(dr3hip_ctx* ctx, const void* d_src, int w, int h, int sstride, int type,
                           void* d_dst, int dstride, int kind, float f);
 
+/* ---- stitch compose: the caller of the 8UC3 warps, reconstruct::Stitch::process (reference src/stitch.cpp:33-80) ---- */
+/* Geometry (:33-71), host-only: Hinv = H.inv() scaled by 1 / Hinv(2,2); bounding box of the right image's corners through
+ * Hinv together with the untransformed corners; canvas size = ceil(max) - floor(min); T = translate(-min_X, -min_Y);
+ * M_right = T * Hinv.  All f32 matrices row-major.  Returns DR3HIP_EINVAL for a singular H (the reference has a TODO there). */
+int dr3hip_stitch_geometry(const float H[9], int w_right, int h_right, float Hinv[9], float T[9], float M_right[9],
+                           int* new_w, int* new_h);
+/* Compose (:72-80) in one kernel: out = addWeighted(warpPerspective(left, T), alpha, warpPerspective(right, M_right), beta,
+ * gamma) on a new_w x new_h 8UC3 canvas (the reference uses alpha = beta = 0.5, gamma = 0).  Host buffers. */
+int dr3hip_stitch_compose(dr3hip_ctx* ctx, const uint8_t* left, int lw, int lh, int lstride,
+                          const uint8_t* right, int rw, int rh, int rstride,
+                          const float T[9], const float M_right[9], int new_w, int new_h,
+                          float alpha, float beta, float gamma, uint8_t* out, int ostride);
+/* the same with device pointers (no copies; enqueued on the ctx stream) */
+int dr3hip_stitch_compose_dev(dr3hip_ctx* ctx, const uint8_t* d_left, int lw, int lh, int lstride,
+                              const uint8_t* d_right, int rw, int rh, int rstride,
+                              const float T[9], const float M_right[9], int new_w, int new_h,
+                              float alpha, float beta, float gamma, uint8_t* d_out, int ostride);
+
 /* ---- panorama paste: reconstruct::Panorama, reference src/panorama.cpp ------------- */
 /* Panorama::set_bbox (src/panorama.cpp:112-138): bounding box of the image corners under the forward
  * f32 homography M, truncated with int().  Host-only. */
@@ -300,7 +318,8 @@ int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on 
 #define DR3HIP_PROF_PANO_ADD  6 /* fused panorama paste kernel                                        */
 #define DR3HIP_PROF_PANO_NORM 7
 #define DR3HIP_PROF_FAST      8 /* FAST score + select kernels of one dr3hip_fast_detect (all levels)   */
-#define DR3HIP_PROF_SLOTS   9
+#define DR3HIP_PROF_STITCH    9 /* fused stitch compose kernel                                        */
+#define DR3HIP_PROF_SLOTS   10
 int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
 int dr3hip_profile_reset(dr3hip_ctx* ctx);

@@ -9,6 +9,7 @@
 //     feature_detection::FastDetector::detect  src/features.cpp:43-98 (src/frame.cpp:57, src/initialization.cpp:552)
 //                                                                 -> dr3hip::FastDetector
 //     utils::warp_spherical / warp_cylindrical  src/utils.cpp:196-201, :267-272 -> dr3hip::warp_spherical / _cylindrical
+//     Stitch::process after align_pair  src/stitch.cpp:33-80       -> dr3hip::stitch_compose
 //     Panorama::paste_images / add_img_to_canvas / normalize_canvas  src/panorama.cpp:143-229
 //                                                                 -> dr3hip::WeightedCanvas
 // Images travel as MatView {data, rows, cols, step, type}: a plain view that a cv::Mat converts to
@@ -212,6 +213,24 @@ inline void create_img_pyramid(const MatView& img_lvl_0, int n_levels, std::vect
     Context& c = Context::instance(device);
     c.check(dr3hip_halfsample_pyramid(c.get(), static_cast<const uint8_t*>(img_lvl_0.data), img_lvl_0.cols, img_lvl_0.rows,
                                       (int)img_lvl_0.step, n_levels, mode, ptrs.data(), strides.data()), "create_img_pyramid");
+}
+
+// reconstruct::Stitch::process after align_pair (src/stitch.cpp:33-80): H is what Stitch::align_pair returned (CV_32F 3x3);
+// fills Hinv (the reference stores it in this->H, :37) and returns the stitched image (this->final_stitched_img, :80).
+inline void stitch_compose(const MatView& left_img, const MatView& right_img, const float H[9], float Hinv[9], Image& stitched, int device = 0)
+{
+    if (left_img.empty() || right_img.empty() || left_img.type != DR3HIP_8UC3 || right_img.type != DR3HIP_8UC3)
+        throw Error(DR3HIP_EINVAL, "stitch_compose: 8UC3 images expected");
+    float T[9], M_right[9];
+    int new_width = 0, new_height = 0;
+    if (dr3hip_stitch_geometry(H, right_img.cols, right_img.rows, Hinv, T, M_right, &new_width, &new_height) != DR3HIP_OK)
+        throw Error(DR3HIP_EINVAL, "stitch_compose: singular homography");
+    stitched.create(new_height, new_width, DR3HIP_8UC3);
+    Context& c = Context::instance(device);
+    c.check(dr3hip_stitch_compose(c.get(), static_cast<const uint8_t*>(left_img.data), left_img.cols, left_img.rows, (int)left_img.step,
+                                  static_cast<const uint8_t*>(right_img.data), right_img.cols, right_img.rows, (int)right_img.step,
+                                  T, M_right, new_width, new_height, 0.5f, 0.5f, 0.0f, stitched.buf.data(), (int)stitched.step),
+            "stitch_compose");
 }
 
 // feature_detection::FastDetector (include/features.hpp:117-130, src/features.cpp:36-98): same constructor

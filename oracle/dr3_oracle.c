@@ -955,3 +955,77 @@ int dr3o_panorama_add(const uint8_t* img, int w, int h, int istride, float* canv
     free(ramp); free(wimg);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Stitch::process after align_pair (src/stitch.cpp:33-80)                                     */
+/* ------------------------------------------------------------------------------------------ */
+static void gemm33_f32(const float A[9], const float B[9], float C[9])   /* CV_32F gemm: double accumulation, one rounding */
+{
+    int i, j, k;
+    float t[9];
+    for (i = 0; i < 3; ++i)
+        for (j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (k = 0; k < 3; ++k) acc += (double)A[3 * i + k] * (double)B[3 * k + j];
+            t[3 * i + j] = (float)acc;
+        }
+    memcpy(C, t, sizeof(t));
+}
+
+int dr3o_stitch_geometry(const float H[9], int w, int h, float Hinv[9], float T[9], float M_right[9], int* new_w, int* new_h)
+{
+    /* cv::invert, CV_32F, n == 3: determinant and cofactors in double, result stored as float */
+    const double d0 = (double)H[0] * ((double)H[4] * H[8] - (double)H[5] * H[7]) - (double)H[1] * ((double)H[3] * H[8] - (double)H[5] * H[6]) +
+                      (double)H[2] * ((double)H[3] * H[7] - (double)H[4] * H[6]);
+    double d;
+    float inv[9], scale, X[8], Y[8], mnx, mny, mxx, mxy;
+    const float cx[4] = {0.f, (float)w, 0.f, (float)w}, cy[4] = {0.f, 0.f, (float)h, (float)h};
+    int i;
+    if (d0 == 0.0) return -1;
+    d = 1.0 / d0;
+    inv[0] = (float)(((double)H[4] * H[8] - (double)H[5] * H[7]) * d); inv[1] = (float)(((double)H[2] * H[7] - (double)H[1] * H[8]) * d);
+    inv[2] = (float)(((double)H[1] * H[5] - (double)H[2] * H[4]) * d); inv[3] = (float)(((double)H[5] * H[6] - (double)H[3] * H[8]) * d);
+    inv[4] = (float)(((double)H[0] * H[8] - (double)H[2] * H[6]) * d); inv[5] = (float)(((double)H[2] * H[3] - (double)H[0] * H[5]) * d);
+    inv[6] = (float)(((double)H[3] * H[7] - (double)H[4] * H[6]) * d); inv[7] = (float)(((double)H[1] * H[6] - (double)H[0] * H[7]) * d);
+    inv[8] = (float)(((double)H[0] * H[4] - (double)H[1] * H[3]) * d);
+    scale = (float)(1.0 / (double)inv[8]);                     /* Hinv * (1.0 / Hinv.at<float>(2,2)): float MatExpr scale */
+    for (i = 0; i < 9; ++i) Hinv[i] = inv[i] * scale;
+    for (i = 0; i < 4; ++i) {                                   /* (Hinv * points^T)^T, divided by the weight (:43-50) */
+        float t[3]; int r;
+        for (r = 0; r < 3; ++r)
+            t[r] = (float)((double)Hinv[3 * r] * (double)cx[i] + (double)Hinv[3 * r + 1] * (double)cy[i] + (double)Hinv[3 * r + 2] * 1.0);
+        X[i] = t[0] / t[2]; Y[i] = t[1] / t[2];
+        X[4 + i] = cx[i]; Y[4 + i] = cy[i];                    /* the untransformed corners (:57-60) */
+    }
+    mnx = mxx = X[0]; mny = mxy = Y[0];
+    for (i = 1; i < 8; ++i) {
+        if (X[i] < mnx) mnx = X[i];
+        if (mxx < X[i]) mxx = X[i];
+        if (Y[i] < mny) mny = Y[i];
+        if (mxy < Y[i]) mxy = Y[i];
+    }
+    *new_w = (int)(ceilf(mxx) - floorf(mnx));                  /* int(std::ceil(max_X) - std::floor(min_X)) on floats */
+    *new_h = (int)(ceilf(mxy) - floorf(mny));
+    T[0] = 1.f; T[1] = 0.f; T[2] = -mnx; T[3] = 0.f; T[4] = 1.f; T[5] = -mny; T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
+    gemm33_f32(T, Hinv, M_right);                              /* translate_top_left_mat * Hinv (:73) */
+    return 0;
+}
+
+int dr3o_stitch_compose(const uint8_t* left, int lw, int lh, int lstride, const uint8_t* right, int rw, int rh, int rstride,
+                        const float T[9], const float M_right[9], int new_w, int new_h, float alpha, float beta, float gamma,
+                        uint8_t* out, int ostride, uint8_t* scratch, int n_threads)
+{
+    uint8_t* wr = scratch;
+    uint8_t* wl = scratch + (size_t)new_w * new_h * 3;
+    int x, y;
+    if (new_w < 1 || new_h < 1) return -1;
+    dr3o_warp_perspective(right, rw, rh, rstride, DR3O_8UC3, wr, new_w, new_h, new_w * 3, M_right, 0, n_threads);   /* :73 */
+    dr3o_warp_perspective(left, lw, lh, lstride, DR3O_8UC3, wl, new_w, new_h, new_w * 3, T, 0, n_threads);          /* :74 */
+    for (y = 0; y < new_h; ++y)                                /* cv::addWeighted(left, alpha, right, beta, gamma) (:80) */
+        for (x = 0; x < new_w * 3; ++x) {
+            const float t = (float)wl[(size_t)y * new_w * 3 + x] * alpha + (float)wr[(size_t)y * new_w * 3 + x] * beta + gamma;
+            const int v = (int)nearbyintf(t);                  /* cvRound: round half to even */
+            out[(size_t)y * ostride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    return 0;
+}

@@ -133,6 +133,18 @@ int  dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int
  * inliers (n bytes, may be NULL).  f32 arithmetic exactly as written, sequential score accumulation. */
 float dr3o_check_fundamental(const float F21[9], const float* pts1, const float* pts2, int n, float sigma, uint8_t* inliers);
 
+/* reconstruct::Stitch::process, the part after align_pair (src/stitch.cpp:33-80).
+ * geometry (:33-71): Hinv = H.inv() (cv::invert, CV_32F 3x3: closed form in double, stored as float), scaled by
+ * 1 / Hinv(2,2) as a float MatExpr; the right image's corners through Hinv (CV_32F gemm: double accumulation, one rounding),
+ * together with the untransformed corners, give min/max; new size = ceil(max) - floor(min); T = translate(-min_X, -min_Y).
+ * M_right = T * Hinv (CV_32F gemm).  Returns 0, or -1 for a singular H (the reference has a TODO there). */
+int  dr3o_stitch_geometry(const float H[9], int w, int h, float Hinv[9], float T[9], float M_right[9], int* new_w, int* new_h);
+/* compose (:72-80): warpPerspective(right, T * Hinv), warpPerspective(left, T), addWeighted(left, 0.5, right, 0.5, 0):
+ * saturate_cast<uchar>(cvRound(l * alpha + r * beta + gamma)) in f32.  out: new_w x new_h 8UC3, scratch 2 * new_w * new_h * 3 */
+int  dr3o_stitch_compose(const uint8_t* left, int lw, int lh, int lstride, const uint8_t* right, int rw, int rh, int rstride,
+                         const float T[9], const float M_right[9], int new_w, int new_h, float alpha, float beta, float gamma,
+                         uint8_t* out, int ostride, uint8_t* scratch, int n_threads);
+
 /* src/utils.cpp:125-187 / :203-265 -- spherical / cylindrical map generation (u,v f32 planes w*h) */
 void dr3o_spherical_map(int w, int h, float f, float* u, float* v);
 void dr3o_cylindrical_map(int w, int h, float f, float* u, float* v);

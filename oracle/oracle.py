@@ -81,6 +81,10 @@ def lib():
         L.dr3o_fast_detect_grid.restype = ip
         L.dr3o_check_fundamental.argtypes = [vp, vp, vp, ip, C.c_float, vp]
         L.dr3o_check_fundamental.restype = C.c_float
+        L.dr3o_stitch_geometry.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
+        L.dr3o_stitch_geometry.restype = ip
+        L.dr3o_stitch_compose.argtypes = [vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip, vp, ip]
+        L.dr3o_stitch_compose.restype = ip
         L.dr3o_panorama_bbox.argtypes = [vp, ip, ip, vp, vp, vp, vp]
         L.dr3o_panorama_bbox.restype = None
         L.dr3o_feather_ramp.argtypes = [ip, ip, ip, vp]
@@ -336,3 +340,27 @@ def check_fundamental(F21, pts1, pts2, sigma=1.0):
     inl = np.zeros(len(p1), np.uint8)
     sc = lib().dr3o_check_fundamental(_p(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(inl))
     return np.float32(sc), inl
+
+
+def stitch_geometry(H, w, h):
+    """Stitch::process geometry (src/stitch.cpp:33-71) -> (Hinv, T, M_right, (new_w, new_h))"""
+    H = np.ascontiguousarray(H, np.float32).reshape(9)
+    Hinv, T, M = (np.zeros(9, np.float32) for _ in range(3))
+    nw, nh = C.c_int(), C.c_int()
+    if lib().dr3o_stitch_geometry(_p(H), int(w), int(h), _p(Hinv), _p(T), _p(M), C.byref(nw), C.byref(nh)) != 0:
+        raise ValueError("singular homography")
+    return Hinv.reshape(3, 3), T.reshape(3, 3), M.reshape(3, 3), (nw.value, nh.value)
+
+
+def stitch_compose(left, right, H, alpha=0.5, beta=0.5, gamma=0.0, n_threads=0):
+    """Stitch::process after align_pair (src/stitch.cpp:33-80): the stitched 8UC3 image"""
+    left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+    _, T, M, (nw, nh) = stitch_geometry(H, right.shape[1], right.shape[0])
+    out = np.zeros((nh, nw, 3), np.uint8)
+    scratch = np.zeros(2 * nw * nh * 3, np.uint8)
+    r = lib().dr3o_stitch_compose(_p(left), left.shape[1], left.shape[0], left.strides[0], _p(right), right.shape[1], right.shape[0],
+                                  right.strides[0], _p(np.ascontiguousarray(T.reshape(9))), _p(np.ascontiguousarray(M.reshape(9))), nw, nh,
+                                  C.c_float(alpha), C.c_float(beta), C.c_float(gamma), _p(out), out.strides[0], _p(scratch), int(n_threads))
+    if r != 0:
+        raise ValueError("stitch_compose failed")
+    return out
