@@ -15,18 +15,32 @@ def _free_port():
     return p
 
 
-def test_two_rank_protocol(tmp_path):
+def _run_two_ranks(tmp_path, extra_env=None):
     port = _free_port()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
     procs, outs = [], []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", **(extra_env or {}))
         outs.append(str(tmp_path / ("r%d.json" % r)))
         procs.append(subprocess.Popen([sys.executable, worker, outs[-1]], env=env))
     for p in procs:
         assert p.wait(timeout=180) == 0
-    res = [json.load(open(o)) for o in outs]
+    return [json.load(open(o)) for o in outs]
+
+
+def test_ref_pyramid_leg_survives_a_failing_rank(tmp_path):
+    """bench.ref_bcast_leg: a rank whose communicator init fails must neither hang the other rank nor go unreported"""
+    res = _run_two_ranks(tmp_path, {"DR3_TEST_FAIL_RANK": "1"})
+    for r in res:
+        assert r["leg"]["ranks_with_error"] == 1 and r["leg"]["identical_on_all_ranks"] is False
+    assert "injected" in res[1]["leg"]["error"] and res[0]["leg"]["error"] is None
+
+
+def test_two_rank_protocol(tmp_path):
+    res = _run_two_ranks(tmp_path)
+    for r in res:                                                     # the reference-pyramid leg: same planes everywhere
+        assert r["leg"]["ranks_with_error"] == 0 and r["leg"]["identical_on_all_ranks"] is True and r["leg"]["bytes_per_rank"] == 4 * 6 * 8
     for r in res:
         assert r["world"] == 2 and r["calls"] == 7                    # 2 warm-up + exactly 5 timed steps
         assert tuple(r["intr"]) == tuple(bench.INTRINSICS)            # rank 1 received rank 0's values
