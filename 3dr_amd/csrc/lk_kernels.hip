@@ -98,10 +98,11 @@ __device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weigh
 {
     const uint32_t p0 = __builtin_amdgcn_perm(r.hi0, r.lo0, sel);
     const uint32_t p1 = __builtin_amdgcn_perm(r.hi1, r.lo1, sel);
-    uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), __builtin_bit_cast(u16x2, W.w01),
-                                        1u << (W_BITS - 5 - 1), false);
-    v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), __builtin_bit_cast(u16x2, W.w23), v, false);
-    return (int)(v >> (W_BITS - 5));
+    // signed dot: iw11 = 2^14 - iw00 - iw01 - iw10 is -1 or -2 when both fractions are a few 1e-5 (the three rounded
+    // weights then sum to more than 2^14); OpenCV carries it as a negative int, so must the packed 16-bit lane
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 5 - 1), false);
+    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, false);
+    return v >> (W_BITS - 5);
 }
 
 // CV_DESCALE(d00*iw00 + d01*iw01 + d10*iw10 + d11*iw11, W_BITS) on one int16 channel of the

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
 
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int first, int n_slots, hipStream_t s)
 {
-    if (n_slots <= 0 || n_lv <= 0) return hipSuccess;
+    if (n_slots <= 0 || n_lv <= 0 || lv[0].pad_x <= 0) return hipSuccess;
     PadArgs a; a.first = first; a.n_lv = n_lv;
     int n_max = 0;
     for (int i = 0; i < n_lv; ++i) {

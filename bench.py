@@ -217,7 +217,10 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per step and per GPU (default 256; 64 for --workload hd)")
+    ap.add_argument("--workload", choices=("kitti", "hd"), default="kitti",
+                    help="kitti = BASELINE configs[1] (the metric's configuration, default); hd = the per-GPU share of configs[4]: "
+                         "1920x1080 pairs, 5000 corners, 5-level pyramid, 21x21 window (default batch 64)")
     ap.add_argument("--no-warp", action="store_true", help="skip the configs[2] warp leg")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detect -> track front-end leg")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-buffer leg (its single-pair launches "
@@ -225,6 +228,18 @@ def main(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args(argv)
+    global N_PTS, WIN, MAX_LEVEL, INTRINSICS
+    grid_cell, period, workload_name = 15, 9, ("configs[1]: KITTI-00-shaped stream 1241x376 u8, 2000 corners/frame, 4-level pyr (maxLevel 3), "
+                                               "15x15 window, 30 LK iters (COUNT+EPS 0.01)")
+    if args.workload == "hd":
+        N_PTS, WIN, MAX_LEVEL = 5000, 21, 4
+        INTRINSICS = (1050.0, 1050.0, 959.5, 539.5, 1920.0, 1080.0)
+        grid_cell, period = 20, 3
+        workload_name = ("configs[4], one GPU's share: batched 1920x1080 u8 pairs, 5000 corners, 5-level pyr (maxLevel 4), 21x21 window, "
+                         "30 LK iters (COUNT+EPS 0.01)")
+        args.no_frontend = True; args.no_warp = True; args.no_host_api = True
+    if args.batch is None:
+        args.batch = 64 if args.workload == "hd" else 256
 
     # torch first: its bundled libamdhip64 and ours share one SONAME, so whichever is loaded first
     # serves both; loading torch's first keeps a single HIP runtime in the process.
@@ -249,12 +264,12 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     # ---- resident inputs ------------------------------------------------------------------------
-    frames, base = stream_frames(synth, B + 1, W, H)
+    frames, base = stream_frames(synth, B + 1, W, H, period=period)
     batch = dr3.FrameBatch(ctx, W, H, win=(WIN, WIN), max_level=MAX_LEVEL, capacity=B + 1)
     levels = batch.levels
     for s0 in range(0, B + 1, 64):
         batch.upload(s0, np.stack(frames[s0:s0 + 64]))
-    pts = synth.grid_points(W, H, 15, n=N_PTS)
+    pts = synth.grid_points(W, H, grid_cell, n=N_PTS)
     P = np.ascontiguousarray(np.broadcast_to(pts[None], (B, N_PTS, 2)), np.float32)
     d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
     d_st, d_err = ctx.alloc(B * N_PTS), ctx.alloc(B * N_PTS * 4)
@@ -370,8 +385,7 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: KITTI-00-shaped stream 1241x376 u8, 2000 corners/frame, "
-                                   "4-level pyr (maxLevel 3), 15x15 window, 30 LK iters (COUNT+EPS 0.01)",
+            "config": {"workload": workload_name,
                        "frame_pairs_per_step_per_gpu": B, "points_per_pair": N_PTS,
                        "sequences": dist.world, "parallelism": "one sequence per GPU, no data-path collective",
                        "intrinsics_bcast": [fx, fy, cx, cy, W, H]},
@@ -389,11 +403,11 @@ def main(argv=None):
                                        "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": ach_pass / HBM_PEAK_GBPS, "traffic": None,
                                        "algorithmic_bytes_per_pass": b_pass, "avg_pass_ms": pass_ms},
-            "lk_kernel": {"kernel": "lk_track_kernel<1>", "avg_launch_ms": lk_ms,
+            "lk_kernel": {"kernel": "lk_track_kernel<%d>" % ((((WIN + 3) // 4) * WIN + 63) // 64), "avg_launch_ms": lk_ms,
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "VALU-issue bound, not HBM-bound (SURVEY 8d): no HBM fraction claimed",
-                          "valu_issue": lk_valu_issue(lk_ms, B * N_PTS)},
+                          "valu_issue": lk_valu_issue(lk_ms, B * N_PTS) if args.workload == "kitti" else None},
             "hbm_copy_measured_GBps": copy_gbps,
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,

@@ -153,6 +153,32 @@ def test_points_on_and_beyond_borders(dr3, O, synth, ctx):
     assert g_st[10] == 0                      # far outside: lost
 
 
+def test_negative_fourth_bilinear_weight(dr3, O, synth, ctx):
+    """iw11 = 2^14 - iw00 - iw01 - iw10 is -1 when both sub-pixel fractions are a few 1e-5 (the three rounded weights sum to
+    2^14 + 1); OpenCV carries it as a negative int.  Regression: the kernel once packed it into an UNSIGNED 16-bit dot lane,
+    which sent one point in 5000 of the 1080p stream 100 px away.  Window offsets that put the template AND the first
+    iterate on such fractions, on every level (the fraction survives the halving for these values)."""
+    A, B, T = synth.frame_pair(480, 300)
+    f32 = np.float32
+    # fractions t with 0.5 / 2^14 < t < 1.5 / 2^15: w00 rounds to 2^14 - 1 while w01 and w10 both round to 1.  Coordinates in
+    # [64, 128) have a float spacing of 2^-17, so 4 .. 5 ulps (3.05e-5 .. 3.8e-5) are exactly representable there
+    fr = np.array([4, 5], f32) * f32(2.0 ** -17) + f32(1e-9)
+    gx, gy = np.meshgrid(np.arange(66, 126, 6, dtype=f32), np.arange(66, 126, 6, dtype=f32))
+    base = np.stack([gx.ravel(), gy.ravel()], 1)
+    pts = np.concatenate([base + np.array([fx, fy], f32) for fx in fr for fy in fr]).astype(f32)
+    # make sure the case is really exercised: some point has all three rounded weights summing past 2^14
+    a, b = pts[:, 0] - np.floor(pts[:, 0]), pts[:, 1] - np.floor(pts[:, 1])
+    w = [np.rint((1 - a) * (1 - b) * f32(16384)), np.rint(a * (1 - b) * f32(16384)), np.rint((1 - a) * b * f32(16384))]
+    assert (16384 - w[0] - w[1] - w[2] < 0).any()
+    for win, ml in (((15, 15), 0), ((21, 21), 0), ((15, 15), 2)):
+        pg, po = _params(dr3, O, win=win, max_level=ml, max_iters=30, eps=0.01)
+        for nxt in (A, B):                                   # A -> A keeps the iterate on the template's own fractions
+            g_xy, g_st, g_err, _ = ctx.calcOpticalFlowPyrLK(A, nxt, pts, None, pg)
+            o_xy, o_st, o_err, _ = O.lk_track(A, nxt, pts, None, po, order=O.ORDER_WAVE64)
+            assert np.array_equal(g_st, o_st) and np.array_equal(g_xy.view(np.uint32), o_xy.view(np.uint32)), (win, ml)
+            assert np.array_equal(g_err.view(np.uint32), o_err.view(np.uint32))
+
+
 def test_flat_image_fails_min_eig(dr3, O, ctx):
     A = np.full((120, 160), 77, np.uint8)
     pts = np.array([[40, 40], [80, 60.5]], np.float32)
