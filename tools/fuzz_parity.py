@@ -1,0 +1,80 @@
+"""randomised parity sweep, GPU vs oracle (bit-exact bars only): LK over random sizes / windows / levels / flags with
+adversarial sub-pixel fractions, warps over random homographies and types, FAST over random images.
+usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dr3 = importlib.import_module("3dr_amd"); synth = importlib.import_module("3dr_amd.synth")
+from oracle import oracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = dr3.Context(0)
+f32 = np.float32
+bad = 0
+
+
+def adversarial_points(w, h, n):
+    p = np.stack([rng.uniform(-4, w + 4, n), rng.uniform(-4, h + 4, n)], 1)
+    kind = rng.integers(0, 6, n)
+    fr = np.array([0.0, 0.5, 2.0 ** -15, 1 - 2.0 ** -15, 3.8e-5, 0.25])
+    for i in range(n):
+        if kind[i] < 5:
+            p[i] = np.floor(p[i]) + fr[rng.integers(0, len(fr), 2)]
+    return p.astype(f32)
+
+
+for case in range(n_cases):
+    # ---- LK
+    w, h = int(rng.integers(40, 700)), int(rng.integers(36, 420))
+    win = (int(rng.integers(3, 33)), int(rng.integers(3, 33)))
+    if ((win[0] + 3) // 4) * win[1] > 256 or w <= win[0] + 2 or h <= win[1] + 2:
+        continue
+    ml = int(rng.integers(0, 6)); flags = int(rng.choice([0, 4, 8, 12]))
+    mot = dict(tx=rng.uniform(-4, 4), ty=rng.uniform(-3, 3), rot_deg=rng.uniform(-1, 1), zoom=rng.uniform(0.98, 1.03))
+    A, B, T = synth.frame_pair(w, h, motion=mot, seed=int(rng.integers(1, 1 << 20)))
+    if rng.random() < 0.3:                         # harsh content: noise + blocks
+        A = np.clip(A.astype(int) + rng.integers(-60, 60, A.shape), 0, 255).astype(np.uint8)
+        B = np.clip(B.astype(int) + rng.integers(-60, 60, B.shape), 0, 255).astype(np.uint8)
+    pts = adversarial_points(w, h, int(rng.integers(1, 400)))
+    guess = (synth.apply_T(T, pts) + rng.normal(0, 0.7, pts.shape)).astype(f32) if flags & 4 else None
+    kw = dict(win=win, max_level=ml, max_iters=int(rng.integers(0, 40)), eps=float(rng.choice([0.0, 0.01, 0.03, 1e-3])), flags=flags)
+    g = ctx.calcOpticalFlowPyrLK(A, B, pts, None if guess is None else guess.copy(), dr3.lk_params(**kw))
+    o = O.lk_track(A, B, pts, None if guess is None else guess.copy(), O.lk_params(**kw), order=O.ORDER_WAVE64)
+    ok = g[3] == o[3] and np.array_equal(g[1], o[1]) and np.array_equal(g[0].view(np.uint32), o[0].view(np.uint32)) and \
+        np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+    if not ok:
+        bad += 1
+        d = np.where((g[0] != o[0]).any(1) | (g[1] != o[1]))[0]
+        print("LK MISMATCH case", case, (w, h), kw, "n_bad", len(d), "first", pts[d[:3]].tolist(), flush=True)
+    # ---- warp
+    t = rng.choice(["u8c3", "u8c1", "f32c4", "u8c4", "f32c1"])
+    shape = {"u8c3": (h, w, 3), "u8c1": (h, w), "f32c4": (h, w, 4), "u8c4": (h, w, 4), "f32c1": (h, w)}[t]
+    src = rng.integers(0, 256, shape, dtype=np.uint8) if t.startswith("u8") else (rng.random(shape, dtype=f32) * 255).astype(f32)
+    ang = rng.uniform(-0.6, 0.6); sc = rng.uniform(0.5, 2.0)
+    M = np.array([[np.cos(ang) * sc, -np.sin(ang) * sc, rng.uniform(-30, 60)], [np.sin(ang) * sc, np.cos(ang) * sc, rng.uniform(-30, 60)],
+                  [rng.uniform(-2e-3, 2e-3), rng.uniform(-2e-3, 2e-3), 1]], f32)
+    if rng.random() < 0.2:
+        M[0, 2] = np.floor(M[0, 2]) + rng.choice([0, 0.5, 1 / 64, 3 / 64]); M[2, :2] = 0; M[:2, :2] = np.eye(2)   # ties everywhere
+    ds = (int(rng.integers(1, 900)), int(rng.integers(1, 500)))
+    fl = int(rng.choice([0, dr3.WARP_INVERSE_MAP]))
+    gw = ctx.warpPerspective(src, M, ds, fl); ow = O.warp_perspective(src, M, ds, O.WARP_INVERSE_MAP if fl else 0)
+    if not np.array_equal(gw.view(np.uint8), ow.view(np.uint8)):
+        bad += 1
+        print("WARP MISMATCH case", case, t, (w, h), ds, fl, M.tolist(), int((gw != ow).sum()), flush=True)
+    # ---- FAST + grid detect
+    img = np.clip(A.astype(int) + rng.integers(-40, 40, A.shape) * (rng.random(A.shape) < 0.1), 0, 255).astype(np.uint8)
+    if w >= 32 and h >= 32:
+        thr = int(rng.integers(5, 60)); nl = int(rng.integers(1, 4)); cell = int(rng.integers(8, 40))
+        if (w >> (nl - 1)) >= 8 and (h >> (nl - 1)) >= 8:
+            og = O.fast_detect_grid(O.halfsample_pyramid(img, nl, O.HALF_REF_X86), cell, thr, 20.0)
+            gg = ctx.fast_detect(img, nl, cell, thr, 20.0)
+            m = og[3] >= 0
+            if not (np.array_equal(gg[3], og[3]) and np.array_equal(gg[0][m], og[0][m]) and np.array_equal(gg[1][m], og[1][m]) and
+                    np.array_equal(gg[2][m].view(np.uint32), og[2][m].view(np.uint32))):
+                bad += 1
+                print("FAST MISMATCH case", case, (w, h), thr, nl, cell, flush=True)
+    if case % 10 == 9:
+        print("case", case + 1, "mismatches so far", bad, flush=True)
+print("done:", n_cases, "cases,", bad, "mismatches")
+sys.exit(1 if bad else 0)
