@@ -414,8 +414,12 @@ __device__ __forceinline__ Tap map_tap(const RemapArgs& a, const float* __restri
         xhat /= zhat; yhat /= zhat;
         u = xhat * a.f + a.half_w; v = yhat * a.f + a.half_h;
     }
-    // cvRound(map * INTER_TAB_SIZE): f32 multiply, round half to even
-    return tap_from_fixed(__float2int_rn(u * 32.f), __float2int_rn(v * 32.f));
+    // cvRound(map * INTER_TAB_SIZE): f32 multiply, round half to even; NaN, infinities and out-of-range products give
+    // x86's "integer indefinite" 0x80000000 there (cvtss2si), not the saturated value of v_cvt_i32_f32
+    const float us = u * 32.f, vs = v * 32.f;
+    const int X = (us >= -2147483648.f && us < 2147483648.f) ? __float2int_rn(us) : (int)0x80000000;
+    const int Y = (vs >= -2147483648.f && vs < 2147483648.f) ? __float2int_rn(vs) : (int)0x80000000;
+    return tap_from_fixed(X, Y);
 }
 
 template <int TYPE, int MAPS>

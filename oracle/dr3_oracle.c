@@ -32,8 +32,10 @@ static inline int reflect101(int p, int len)
     return p;
 }
 
-static inline int cv_round_f(float v)  { return (int)lrintf(v); }  /* cvRound(float): half-to-even */
-static inline int cv_round_d(double v) { return (int)lrint(v); }   /* cvRound(double) / saturate_cast<int>(double) */
+/* cvRound on x86-64 is cvtss2si / cvtsd2si with a 32-bit destination: round half to even, and the "integer indefinite"
+ * 0x80000000 for NaN, infinities and anything outside the int range (a 64-bit lrint would wrap instead). */
+static inline int cv_round_f(float v)  { return (v >= -2147483648.f && v < 2147483648.f) ? (int)lrintf(v) : (int)0x80000000; }
+static inline int cv_round_d(double v) { return (v >= -2147483648.0 && v < 2147483647.5) ? (int)lrint(v) : (int)0x80000000; }
 static inline int cv_floor_f(float v)  { return (int)floorf(v); }
 
 static inline short sat_s16(int v)
@@ -757,8 +759,9 @@ int dr3o_warp_perspective(const void* src_, int sw, int sh, int sstride, int typ
             int X, Y;
             W = W ? 32. / W : 0;
             fX = (X0 + M[0] * x1) * W; fY = (Y0 + M[3] * x1) * W;
-            fX = fX < (double)INT_MIN ? (double)INT_MIN : fX > (double)INT_MAX ? (double)INT_MAX : fX;
-            fY = fY < (double)INT_MIN ? (double)INT_MIN : fY > (double)INT_MAX ? (double)INT_MAX : fY;
+            /* std::max((double)INT_MIN, std::min((double)INT_MAX, v)) with the std:: argument order: a NaN becomes INT_MAX */
+            fX = (fX < (double)INT_MAX) ? fX : (double)INT_MAX; fX = ((double)INT_MIN < fX) ? fX : (double)INT_MIN;
+            fY = (fY < (double)INT_MAX) ? fY : (double)INT_MAX; fY = ((double)INT_MIN < fY) ? fY : (double)INT_MIN;
             X = cv_round_d(fX); Y = cv_round_d(fY);
             sample_px(src, sw, sh, sstride, type, cn, sat_s16(X >> 5), sat_s16(Y >> 5), X & 31, Y & 31,
                       dst + (size_t)y * dstride + (size_t)x * esz);

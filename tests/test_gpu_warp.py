@@ -111,6 +111,10 @@ def test_remap_bit_exact(dr3, O, ctx, shape, dtype):
     mx = rng.uniform(-3, w + 3, (57, 93)).astype(np.float32)
     my = rng.uniform(-3, h + 3, (57, 93)).astype(np.float32)
     mx[0, :8] = [0, 0.5, w - 1, w - 0.5, -1, -0.5, 1e9, -1e9]          # ties and saturating coordinates
+    # non-finite and out-of-int-range map entries: cvRound is cvtss2si on x86-64, whose result for them is 0x80000000
+    # (far outside on the left -> border 0), not the saturated value of the GPU's own conversion
+    mx[1, :6] = [np.inf, -np.inf, np.nan, 3e9, -3e9, 7e7]
+    my[2, :6] = [np.inf, -np.inf, np.nan, 3e9, -3e9, 7e7]
     assert _eq(ctx.remap(src, mx, my), O.remap(src, mx, my))
 
 

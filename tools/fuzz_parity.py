@@ -74,6 +74,45 @@ for case in range(n_cases):
                     np.array_equal(gg[2][m].view(np.uint32), og[2][m].view(np.uint32))):
                 bad += 1
                 print("FAST MISMATCH case", case, (w, h), thr, nl, cell, flush=True)
+    # ---- remap with hostile maps, fused spherical / cylindrical, panorama paste, stitch compose
+    if w >= 16 and h >= 16:
+        c3 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mh, mw = int(rng.integers(1, 200)), int(rng.integers(1, 300))
+        mx = rng.uniform(-8, w + 8, (mh, mw)).astype(f32); my = rng.uniform(-8, h + 8, (mh, mw)).astype(f32)
+        sp = rng.random((mh, mw))
+        mx[sp < 0.02] = rng.choice(np.array([0, 0.5, -0.5, w - 1, w - 0.5, 1e9, -1e9, 40000.0, -40000.0, np.inf, -np.inf, np.nan], f32), int((sp < 0.02).sum()))
+        my[(sp > 0.98)] = rng.choice(np.array([0, 0.5, h - 1, h - 0.5, 1e9, -1e9, np.inf], f32), int((sp > 0.98).sum()))
+        src_r = c3 if rng.random() < 0.6 else c3[..., 0].copy()
+        if not np.array_equal(ctx.remap(src_r, mx, my), O.remap(src_r, mx, my)):
+            bad += 1; print("REMAP MISMATCH case", case, (w, h), (mw, mh), flush=True)
+        fl_ = float(rng.uniform(0.3, 3.0) * w)
+        for kind, fg, fo in (("sph", ctx.warp_spherical, O.spherical_map), ("cyl", ctx.warp_cylindrical, O.cylindrical_map)):
+            u_, v_ = fo(w, h, fl_)
+            if not np.array_equal(fg(c3, fl_), O.remap(c3, u_, v_)):
+                bad += 1; print("MAPGEN MISMATCH case", case, kind, (w, h), fl_, flush=True)
+        Mp = M.copy(); Mp[:2, :2] /= max(sc, 1e-3); Mp[0, 2] = rng.uniform(-0.5 * w, 1.5 * w); Mp[1, 2] = rng.uniform(-20, 60); Mp[2, :2] *= 0.05
+        cw, ch = int(rng.integers(w, 3 * w)), int(rng.integers(h, 2 * h))
+        box = O.panorama_bbox(Mp, w, h)
+        if box[2] - box[0] >= 2:
+            fw = int(rng.integers(0, 80))
+            want = np.zeros((ch, cw, 4), f32)
+            want[...] = rng.random((ch, cw, 4), dtype=f32) * (rng.random() < 0.5)
+            start = want.copy()
+            O.panorama_add(c3, want, Mp, fw)
+            d_c = ctx.to_device(start); d_i = ctx.to_device(c3); d_o = ctx.alloc(cw * ch * 3)
+            ctx.panorama_add(d_i, w, h, 3 * w, d_c, cw, ch, cw * 16, Mp, fw)
+            ctx.panorama_normalize(d_c, cw, ch, cw * 16, d_o, cw * 3)
+            gc_ = d_c.download((ch, cw, 4), f32); gp_ = d_o.download((ch, cw, 3), np.uint8)
+            d_c.free(); d_i.free(); d_o.free()
+            if not (np.array_equal(gc_.view(np.uint32), want.view(np.uint32)) and np.array_equal(gp_, O.normalize_canvas(want))):
+                bad += 1; print("PASTE MISMATCH case", case, (w, h), (cw, ch), fw, Mp.tolist(), flush=True)
+        Hs = Mp.copy(); Hs[0, 2] = -rng.uniform(0.1, 0.7) * w
+        try:
+            ow_ = O.stitch_compose(c3, np.roll(c3, 5, 1), Hs)
+            if ow_.shape[0] * ow_.shape[1] < 4e6 and not np.array_equal(ctx.stitch_compose(c3, np.roll(c3, 5, 1), Hs), ow_):
+                bad += 1; print("STITCH MISMATCH case", case, (w, h), Hs.tolist(), flush=True)
+        except ValueError:
+            pass
     if case % 10 == 9:
         print("case", case + 1, "mismatches so far", bad, flush=True)
 print("done:", n_cases, "cases,", bad, "mismatches")
