@@ -113,6 +113,29 @@ for case in range(n_cases):
                 bad += 1; print("STITCH MISMATCH case", case, (w, h), Hs.tolist(), flush=True)
         except ValueError:
             pass
+    # ---- half-sample pyramid in every mode on odd / even sizes, and the device-resident batched detector on pitched slots
+    if w >= 48 and h >= 48:
+        nl2 = int(rng.integers(2, 4))
+        for mode in ("HALF_TRUNC", "HALF_SSE2", "HALF_REF_SCALAR", "HALF_REF_X86"):
+            gp = ctx.create_img_pyramid(img, nl2, getattr(dr3, mode)); op = O.halfsample_pyramid(img, nl2, getattr(O, mode))
+            if not all(np.array_equal(a_, b_) for a_, b_ in zip(gp, op)):
+                bad += 1; print("HALFSAMPLE MISMATCH case", case, (w, h), mode, flush=True)
+        nf = 2
+        fbatch = dr3.FrameBatch(ctx, w, h, win=(5, 5), max_level=1, capacity=nf)
+        fr2 = [img, np.ascontiguousarray(img[::-1])]
+        fbatch.upload(0, np.stack(fr2)); fbatch.build(0, nf, True)
+        cell2 = int(rng.integers(8, 40)); thr2 = int(rng.integers(8, 50))
+        gc2, gr2 = -(-w // cell2), -(-h // cell2)
+        d_c2 = ctx.alloc(nf * gc2 * gr2 * 16)
+        fbatch.detect(0, nf, nl2, cell2, thr2, 20.0, d_corners=d_c2); ctx.sync()
+        cor = d_c2.download((nf, gc2 * gr2), np.dtype([("x", np.int32), ("y", np.int32), ("level", np.int32), ("score", np.float32)]))
+        for i_ in range(nf):
+            og2 = O.fast_detect_grid(O.halfsample_pyramid(fr2[i_], nl2, O.HALF_REF_X86), cell2, thr2, 20.0)
+            m2 = og2[3] >= 0
+            if not (np.array_equal(cor["level"][i_], og2[3]) and np.array_equal(cor["x"][i_][m2], og2[0][m2]) and
+                    np.array_equal(cor["y"][i_][m2], og2[1][m2]) and np.array_equal(cor["score"][i_][m2].view(np.uint32), og2[2][m2].view(np.uint32))):
+                bad += 1; print("BATCH DETECT MISMATCH case", case, (w, h), nl2, cell2, thr2, i_, flush=True)
+        d_c2.free(); fbatch.close()
     if case % 10 == 9:
         print("case", case + 1, "mismatches so far", bad, flush=True)
 print("done:", n_cases, "cases,", bad, "mismatches")
