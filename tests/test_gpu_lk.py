@@ -266,3 +266,35 @@ def test_batch_stream_matches_pairwise(dr3, O, synth, ctx):
         for d in bufs:
             d.free()
         b.close()
+
+
+def test_batch_track_with_slot_indirection(dr3, O, synth, ctx):
+    """dr3hip_batch_track's prev_slot / next_slot arrays: one keyframe against many candidates (SURVEY 8e's pattern), a
+    reversed pair and a self pair in ONE launch, with per-level iteration counts; every pair equals the oracle bit for bit"""
+    w, h, n_fr = 400, 260, 5
+    frames, T = synth.frame_stream(n_fr, w, h)
+    pts = synth.grid_points(w, h, 26, n=120)
+    n = len(pts)
+    pg, po = _params(dr3, O, win=(15, 15), max_level=2, max_iters=30, eps=0.01)
+    pairs = [(0, 1), (0, 2), (0, 3), (0, 4), (3, 2), (4, 4), (2, 0)]
+    b = dr3.FrameBatch(ctx, w, h, win=(15, 15), max_level=2, capacity=n_fr)
+    bufs = []
+    try:
+        b.upload(0, np.stack(frames)); b.build(0, n_fr, True)
+        P = np.tile(pts[None], (len(pairs), 1, 1)).astype(np.float32)
+        d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+        d_ps = ctx.to_device(np.array([p[0] for p in pairs], np.int32)); d_ns = ctx.to_device(np.array([p[1] for p in pairs], np.int32))
+        d_st, d_err, d_it = ctx.alloc(len(pairs) * n), ctx.alloc(len(pairs) * n * 4), ctx.alloc(len(pairs) * n * 3 * 4)
+        bufs = [d_prev, d_next, d_ps, d_ns, d_st, d_err, d_it]
+        L = b.track(len(pairs), 0, d_prev, d_next, n, d_st, d_err, pg, d_prev_slot=d_ps, d_next_slot=d_ns, d_iters=d_it)
+        ctx.sync()
+        xy = d_next.download((len(pairs), n, 2), np.float32); st = d_st.download((len(pairs), n), np.uint8)
+        er = d_err.download((len(pairs), n), np.float32); it = d_it.download((len(pairs), n, L + 1), np.int32)
+        for i, (ps, ns) in enumerate(pairs):
+            o_xy, o_st, o_err, _, o_it = O.lk_track(frames[ps], frames[ns], pts, None, po, order=O.ORDER_WAVE64, want_iters=True)
+            assert np.array_equal(st[i], o_st) and np.array_equal(xy[i].view(np.uint32), o_xy.view(np.uint32)), (ps, ns)
+            assert np.array_equal(er[i].view(np.uint32), o_err.view(np.uint32)) and np.array_equal(it[i], o_it), (ps, ns)
+    finally:
+        for d in bufs:
+            d.free()
+        b.close()

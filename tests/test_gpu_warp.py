@@ -153,3 +153,38 @@ def test_fused_map_generation_matches_maps_then_remap(dr3, O, ctx, synth, kind, 
     assert _eq(got, want)
     assert np.array_equal(ctx.remap(img, u, v) if img.dtype == np.uint8 else got, got)      # and the map-driven kernel agrees
     assert got.any()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_batch_heterogeneous_jobs_one_launch(dr3, O, ctx, dtype):
+    """dr3hip_warp_perspective_batch (what the bench's configs[2] leg calls): jobs of different source and destination sizes
+    in ONE launch -- the grid is sized for the largest job, the others are bounded per job -- including a destination lower
+    than 16 rows (generic block origin), a map whose W changes sign (exact coordinate path) and a pitched destination"""
+    rng = np.random.default_rng(77)
+    typ, cn = (dr3.T_8UC3, 3) if dtype == np.uint8 else (dr3.T_32FC4, 4)
+    esz = cn * np.dtype(dtype).itemsize
+    specs = [((60, 80), (104, 72)), ((200, 150), (90, 210)), ((33, 47), (300, 11)), ((120, 90), (64, 64)), ((90, 40), (257, 130))]
+    jobs, keep, want = [], [], []
+    for i, ((sw, sh), (dw, dh)) in enumerate(specs):
+        src = rng.integers(0, 256, (sh, sw, cn), dtype=np.uint8) if dtype == np.uint8 else (rng.random((sh, sw, cn), dtype=np.float32) * 255).astype(np.float32)
+        M = _rand_H(rng, sw / 80)
+        if i == 3:
+            M[2] = [0.02, 0.01, 1.0]                                    # W crosses 0 inside the destination
+        dpitch = (dw * esz + 255) // 256 * 256
+        d_src, d_dst = ctx.to_device(src), ctx.alloc(dpitch * dh)
+        d_dst.zero()
+        keep += [d_src, d_dst]
+        jobs.append(dict(src=d_src.ptr, sw=sw, sh=sh, sstride=sw * esz, dst=d_dst.ptr, dw=dw, dh=dh, dstride=dpitch, M=M))
+        want.append(O.warp_perspective(src, M, (dw, dh)))
+    try:
+        dr3.warp_batch(ctx, jobs, typ)
+        ctx.sync()
+        for i, ((sw, sh), (dw, dh)) in enumerate(specs):
+            dpitch = jobs[i]["dstride"]
+            raw = keep[2 * i + 1].download((dh, dpitch), np.uint8)
+            got = np.ascontiguousarray(raw[:, :dw * esz]).view(dtype).reshape(dh, dw, cn)
+            assert _eq(got, want[i]), i
+            assert not raw[:, dw * esz:].any()                             # nothing written past a job's own width
+    finally:
+        for d in keep:
+            d.free()
