@@ -26,7 +26,7 @@ def adversarial_points(w, h, n):
 
 for case in range(n_cases):
     # ---- LK
-    w, h = int(rng.integers(40, 700)), int(rng.integers(36, 420))
+    w, h = int(rng.integers(40, int(os.environ.get("FUZZ_MAXW", "700")))), int(rng.integers(36, int(os.environ.get("FUZZ_MAXH", "420"))))
     win = (int(rng.integers(3, 33)), int(rng.integers(3, 33)))
     if ((win[0] + 3) // 4) * win[1] > 256 or w <= win[0] + 2 or h <= win[1] + 2:
         continue
@@ -36,7 +36,7 @@ for case in range(n_cases):
     if rng.random() < 0.3:                         # harsh content: noise + blocks
         A = np.clip(A.astype(int) + rng.integers(-60, 60, A.shape), 0, 255).astype(np.uint8)
         B = np.clip(B.astype(int) + rng.integers(-60, 60, B.shape), 0, 255).astype(np.uint8)
-    pts = adversarial_points(w, h, int(rng.integers(1, 400)))
+    pts = adversarial_points(w, h, int(rng.integers(1, int(os.environ.get("FUZZ_MAXPTS", "400")))))
     guess = (synth.apply_T(T, pts) + rng.normal(0, 0.7, pts.shape)).astype(f32) if flags & 4 else None
     kw = dict(win=win, max_level=ml, max_iters=int(rng.integers(0, 40)), eps=float(rng.choice([0.0, 0.01, 0.03, 1e-3])), flags=flags)
     g = ctx.calcOpticalFlowPyrLK(A, B, pts, None if guess is None else guess.copy(), dr3.lk_params(**kw))
