@@ -5,7 +5,10 @@ The product is ``libdr3hip.so`` (hand-written HIP kernels + the C entry points o
 and the bench; its function names follow the calls the reference makes
 (``cv::calcOpticalFlowPyrLK`` at src/initialization.cpp:608, ``cv::warpPerspective`` at
 src/stitch.cpp:73-74 / src/panorama.cpp:192, ``cv::remap`` at src/utils.cpp:191,
-``utils::create_img_pyramid`` at src/utils.cpp:421).
+``utils::create_img_pyramid`` at src/utils.cpp:421, ``FastDetector::detect`` at src/features.cpp:43,
+``Panorama::add_img_to_canvas`` / ``normalize_canvas`` at src/panorama.cpp:156-229, ``Stitch::process`` at
+src/stitch.cpp:33-80, ``utils::warp_spherical`` / ``warp_cylindrical`` at src/utils.cpp:196-272,
+``InitHelper::CheckFundamental`` at src/initialization.cpp:171-249).
 
 There is NO CPU fallback: every compute entry point needs the built library and a HIP device and
 raises ``Dr3HipError`` otherwise.  (The directory name starts with a digit, so import it with

@@ -8,10 +8,16 @@ tracking of the B consecutive frame pairs, 2000 points each.  Inputs (level-0 fr
 resident in HBM before the timed region starts.  value = tracked keypoints / s over the whole job.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank streams its own sequence
-(configs[3], weak scaling); the only collective is one RCCL broadcast of the camera intrinsics.
-The JSON line also carries the warp throughput of configs[2] (8 tiles 4000x3000), the HBM roofline
-of the dominant HBM-bound kernel measured with HIP events on the library's stream, and the CPU
-baseline (the oracle port, all host cores, bounded sample).
+(configs[3], weak scaling); the only collective before the timed region is one RCCL broadcast of the
+camera intrinsics (the reference-pyramid broadcast of SURVEY 8e is exercised once, untimed, afterwards).
+The JSON line also carries: the HBM roofline of the dominant HBM-bound kernel (fused pyrDown + Scharr,
+level 0) measured with HIP events on the library's stream and its PMC traffic; the tracker against the
+VALU issue roofline; the warp legs of configs[2] (8 tiles 4000x3000 as 8UC3 and 32FC4, 256 KITTI-sized
+frames -- the "warped Mpix/s on 1241x376 frames" half of the metric --, the fused panorama paste and the
+fused stitch compose); the device-resident front end (pyramids + FAST detect + track); the host-buffer
+call with PCIe included; a measured device-to-device copy bandwidth; and the CPU baseline (the oracle
+port on all host cores and on one thread, bounded sample).  --workload hd runs one GPU's share of
+configs[4] (1920x1080, 5000 corners, 5 levels, 21x21) instead.
 """
 import argparse
 import importlib
@@ -26,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (a measured copy rate is reported as hbm_copy_measured_GBps)
 
 KITTI_W, KITTI_H = 1241, 376
 N_PTS, WIN, MAX_LEVEL, MAX_ITERS, EPS = 2000, 15, 3, 30, 0.01
