@@ -146,6 +146,35 @@ int main(int argc, char** argv)
             wr(fo, dims, 2);
             wr(fo, pyr[l].buf.data(), pyr[l].buf.size());
         }
+        // ---- (4) the rest of the C++14 layer, in the order the reference's demo mains use it ---------------------
+        // tests/test_stitch.cpp -> Stitch::process (src/stitch.cpp:33-80) with the homography align_pair would return
+        {
+            float Hs[9]; rd(fi, Hs, 9);
+            float Hinv[9];
+            dr3hip::Image stitched;
+            dr3hip::MatView left(img.data(), th, tw, (size_t)tw * 3, DR3HIP_8UC3);       // the panorama tile doubles as both images
+            dr3hip::stitch_compose(left, left, Hs, Hinv, stitched);
+            int dims[2] = {stitched.cols, stitched.rows};
+            wr(fo, dims, 2); wr(fo, Hinv, 9);
+            wr(fo, stitched.buf.data(), stitched.buf.size());
+        }
+        // tests/test_panorama.cpp spherical pre-warp: utils::warp_spherical(img, f) (src/utils.cpp:196-201)
+        {
+            float focal; rd(fi, &focal, 1);
+            dr3hip::Image sph;
+            dr3hip::warp_spherical(dr3hip::MatView(img.data(), th, tw, (size_t)tw * 3, DR3HIP_8UC3), focal, sph);
+            wr(fo, sph.buf.data(), sph.buf.size());
+        }
+        // Frame::Frame -> FastDetector::detect (src/frame.cpp:57): cell 30, 3 levels, min_harris_corner_score 20 (src/config.cpp:10-12)
+        {
+            dr3hip::FastDetector detector(w, h, 30, 3);
+            detector.flag_grid(100.0, 50.0);                                               // an existing feature occupies its cell (:29-33)
+            std::vector<dr3hip::Corner> corners;
+            detector.detect(mref, 20.0, corners);
+            const int nc = (int)corners.size();
+            wr(fo, &nc, 1);
+            for (const auto& c : corners) { int v[3] = {c.x, c.y, c.level}; wr(fo, v, 3); wr(fo, &c.score, 1); }
+        }
         fprintf(stderr, "harness: %d/%d points tracked, %zu outliers, canvas %dx%d\n", n_kept, n, outlier_count, W, H);
     } catch (const dr3hip::Error& e) {
         fprintf(stderr, "dr3hip error %d: %s\n", e.code, e.what());

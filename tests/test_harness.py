@@ -55,6 +55,8 @@ def test_harness_matches_oracle(dr3, O, synth, tmp_path):
         np.array([w, h, len(pts)], np.int32).tofile(f); A.tofile(f); B.tofile(f); pts.astype(np.float32).tofile(f)
         np.array([tw, th, W, H, feather], np.int32).tofile(f); tile.tofile(f); M.astype(np.float32).tofile(f)
         np.array([min_x, max_x], np.int32).tofile(f)
+        Hs = np.array([[0.999, -0.02, -70.5], [0.02, 0.999, 6.25], [2e-5, -1e-5, 1]], np.float32)
+        Hs.tofile(f); np.array([175.0], np.float32).tofile(f)
     r = subprocess.run([EXE, fin, fout], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
 
@@ -70,6 +72,12 @@ def test_harness_matches_oracle(dr3, O, synth, tmp_path):
         for _ in range(2):
             cw, ch = np.fromfile(f, np.int32, 2)
             levels.append(np.fromfile(f, np.uint8, cw * ch).reshape(ch, cw))
+        sw_, sh_ = np.fromfile(f, np.int32, 2)
+        hinv = np.fromfile(f, np.float32, 9).reshape(3, 3)
+        stitched = np.fromfile(f, np.uint8, sw_ * sh_ * 3).reshape(sh_, sw_, 3)
+        sph = np.fromfile(f, np.uint8, tw * th * 3).reshape(th, tw, 3)
+        nc = int(np.fromfile(f, np.int32, 1)[0])
+        corners = np.fromfile(f, np.dtype([("x", np.int32), ("y", np.int32), ("level", np.int32), ("score", np.float32)]), nc)
 
     # (1) LK with the reference literals, identity initial guess, then the erase loop
     po = O.lk_params(win=(30, 30), max_level=4, max_iters=1000, eps=1e-3, flags=O.LK_USE_INITIAL_FLOW)
@@ -96,6 +104,18 @@ def test_harness_matches_oracle(dr3, O, synth, tmp_path):
     O.panorama_add(tile, canvas2, M, feather)
     assert np.array_equal(pano_fused, O.normalize_canvas(canvas2))
     assert O.panorama_bbox(M, tw, th)[0::2] == (min_x, max_x) and np.array_equal(pano_fused, pano)
+
+    # (4) stitch compose, spherical pre-warp and the FAST detector through the C++14 layer
+    o_hinv, _, _, o_size = O.stitch_geometry(Hs, tw, th)
+    assert (sw_, sh_) == o_size and np.array_equal(hinv.view(np.uint32), o_hinv.view(np.uint32))
+    assert np.array_equal(stitched, O.stitch_compose(tile, tile, Hs))
+    assert np.array_equal(sph, O.remap(tile, *O.spherical_map(tw, th, 175.0)))
+    gc_ = -(-w // 30)
+    occ = np.zeros(gc_ * -(-h // 30), np.uint8); occ[int(50 / 30) * gc_ + int(100 / 30)] = 1
+    ox, oy, osc, ol = O.fast_detect_grid(O.halfsample_pyramid(A, 3, O.HALF_REF_X86), 30, 20, 20.0, occ)
+    m = ol >= 0
+    assert nc == int(m.sum()) and np.array_equal(corners["x"], ox[m]) and np.array_equal(corners["y"], oy[m])
+    assert np.array_equal(corners["level"], ol[m]) and np.array_equal(corners["score"].view(np.uint32), osc[m].view(np.uint32))
 
     # (3) Frame-constructor pyramid, byte-for-byte what the reference computes on x86-64
     ref_pyr = O.halfsample_pyramid(A, 3, O.HALF_REF_X86)
