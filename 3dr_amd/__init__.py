@@ -127,6 +127,7 @@ def _signatures():
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
         "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
+        "dr3hip_panorama_add_slab": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip, ip, ip], ip),
         "dr3hip_panorama_normalize": ([vp, vp, ip, ip, ip, vp, ip], ip),
         "dr3hip_comm_unique_id": ([vp, vp], ip),
         "dr3hip_comm_init": ([vp, vp, ip, ip], ip),
@@ -325,6 +326,13 @@ class Context:
         ptr = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
         self._chk(lib().dr3hip_panorama_add(self.h, ptr(d_img), w, h, istride, ptr(d_canvas), cw, ch, cstride,
                                             _p(M), int(feathering_width)))
+
+    def panorama_add_slab(self, d_img, w, h, istride, d_slab, cw, ch, cstride, M, feathering_width, y0, y1):
+        """the paste restricted to canvas rows [y0, y1) held in d_slab (one GPU's share of the canvas)"""
+        M = np.ascontiguousarray(M, np.float32).reshape(9)
+        ptr = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b
+        self._chk(lib().dr3hip_panorama_add_slab(self.h, ptr(d_img), w, h, istride, ptr(d_slab), cw, ch, cstride,
+                                                 _p(M), int(feathering_width), int(y0), int(y1)))
 
     def panorama_normalize(self, d_canvas, cw, ch, cstride, d_out, ostride):
         ptr = lambda b: b.ptr if isinstance(b, DeviceBuffer) else b

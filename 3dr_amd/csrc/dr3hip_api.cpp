@@ -529,8 +529,16 @@ int dr3hip_panorama_ramp(int min_x, int max_x, int feathering_width, float* ramp
 int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
                         float* d_canvas, int cw, int ch, int cstride, const float M[9], int feathering_width)
 {
+    return dr3hip_panorama_add_slab(ctx, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, feathering_width, 0, ch);
+}
+
+int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
+                             float* d_canvas, int cw, int ch, int cstride, const float M[9], int feathering_width,
+                             int slab_y0, int slab_y1)
+{
     if (!ctx) return DR3HIP_EINVAL;
-    if (!d_img || !d_canvas || !M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || cstride < 16 * cw)
+    if (!d_img || !d_canvas || !M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || cstride < 16 * cw ||
+        slab_y0 < 0 || slab_y1 > ch || slab_y0 >= slab_y1)
         return fail(ctx, DR3HIP_EINVAL, "panorama_add: bad arguments");
     if ((((uintptr_t)d_canvas | (uintptr_t)cstride) & 15) != 0) return fail(ctx, DR3HIP_EINVAL, "panorama_add: canvas rows must be 16-byte aligned");
     int min_x, min_y, max_x, max_y;
@@ -573,6 +581,9 @@ int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int
             a.cy1 = hi > ch ? ch : (hi < 0.0 ? 0 : (int)hi);
         }
     }
+    a.slab_y0 = slab_y0;                                                 // only rows [slab_y0, slab_y1) live in d_canvas
+    if (a.cy0 < slab_y0) a.cy0 = slab_y0;
+    if (a.cy1 > slab_y1) a.cy1 = slab_y1;
     a.ramp = (const float*)ctx->stage[6].p;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PANO_ADD, pe);
     HIPCHK(ctx, launch_panorama_add(a, ctx->stream));

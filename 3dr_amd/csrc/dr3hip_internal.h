@@ -81,6 +81,7 @@ struct PanoAddArgs {       // fused Panorama::add_img_to_canvas (src/panorama.cp
     double M[9];        int bw0, bw0_shift, fast; // inverse map + WarpPerspectiveInvoker block split, as WarpJobDev
     int cx0, cx1;                                 // canvas columns [cx0, cx1) = [min_x, max_x) clipped to the canvas
     int cy0, cy1;                                 // canvas rows that can receive a non-zero sample (host bound; all rows if unsure)
+    int slab_y0;                                  // canvas row that `canvas` points at (0 unless a GPU owns a slab of rows)
     int min_x;                                    // ramp[x - min_x]
     const float* ramp;                            // device, max_x - min_x entries
 };

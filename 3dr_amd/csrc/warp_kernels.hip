@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256) void panorama_add_kernel(const PanoAddArgs a)
         o[c] = (v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]) * r;
     }
     if (o[0] == 0.f && o[1] == 0.f && o[2] == 0.f) return;               // :205-207
-    DR3_G f32x4* cp = reinterpret_cast<DR3_G f32x4*>((gu8)reinterpret_cast<uint8_t*>(a.canvas) + (long long)y * a.cstride) + x;
+    // a.canvas addresses row a.slab_y0 of the canvas (a GPU may own just a slab of rows)
+    DR3_G f32x4* cp = reinterpret_cast<DR3_G f32x4*>((gu8)reinterpret_cast<uint8_t*>(a.canvas) + (long long)(y - a.slab_y0) * a.cstride) + x;
     f32x4 c4 = *cp;
     c4.x += o[0]; c4.y += o[1]; c4.z += o[2]; c4.w += r;
     *cp = c4;

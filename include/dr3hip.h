@@ -277,6 +277,13 @@ int dr3hip_panorama_ramp(int min_x, int max_x, int feathering_width, float* ramp
 int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
                         float* d_canvas, int cw, int ch, int cstride,
                         const float M[9], int feathering_width);
+/* The same for a GPU that owns only rows [slab_y0, slab_y1) of the cw x ch canvas (canvas tiles are sharded
+ * over GPUs, every GPU pastes all contributing images into its own rows, so no reduction is needed): d_canvas points at
+ * row slab_y0.  The geometry (bounding box, ramp, block split of the warp) is that of the whole canvas, so the slabs of
+ * all GPUs put together equal the single-GPU canvas bit for bit. */
+int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
+                             float* d_canvas, int cw, int ch, int cstride,
+                             const float M[9], int feathering_width, int slab_y0, int slab_y1);
 /* Panorama::normalize_canvas (src/panorama.cpp:215-229): 32FC4 weighted canvas -> 8UC3 panorama. */
 int dr3hip_panorama_normalize(dr3hip_ctx* ctx, const float* d_canvas, int cw, int ch, int cstride,
                               uint8_t* d_out, int ostride);

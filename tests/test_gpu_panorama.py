@@ -102,3 +102,25 @@ def test_bad_arguments_return_errors(dr3, ctx):
     finally:
         for d in (d_img, d_c, d_o):
             d.free()
+
+
+def test_canvas_slabs_of_several_gpus_equal_the_whole_canvas(dr3, O, ctx, synth):
+    """SURVEY 8(e), warp side: the canvas is sharded by rows, every GPU pastes all images into its own slab, nothing is
+    reduced.  Three slabs (as three GPUs would hold them) put together equal the single canvas bit for bit."""
+    rng = np.random.default_rng(12)
+    imgs, Ms = _scene(synth, 3, 160, 120, rng)
+    cw, ch = 460, 170
+    want = np.zeros((ch, cw, 4), np.float32)
+    for img, M in zip(imgs, Ms):
+        O.panorama_add(img, want, M, 25)
+    bounds = [0, 57, 58, ch]                                   # uneven slabs, one of a single row
+    got = np.zeros_like(want)
+    for y0, y1 in zip(bounds[:-1], bounds[1:]):
+        d_slab = ctx.alloc((y1 - y0) * cw * 16); d_slab.zero()
+        for img, M in zip(imgs, Ms):
+            d_img = ctx.to_device(img)
+            ctx.panorama_add_slab(d_img, 160, 120, 480, d_slab, cw, ch, cw * 16, M, 25, y0, y1)
+            ctx.sync(); d_img.free()
+        got[y0:y1] = d_slab.download((y1 - y0, cw, 4), np.float32)
+        d_slab.free()
+    assert np.array_equal(_bits(got), _bits(want)) and got[..., 3].max() >= 1.0
