@@ -221,3 +221,34 @@ def test_oracle_matches_numpy_restatement_on_the_reference_kitti_pair(O):
     o_xy, o_st, o_err, _ = O.lk_track(A, B, pts, None, po, order=O.ORDER_RASTER)
     n_xy, n_st, n_err, _ = R.lk_track(A, B, pts, None, win=(21, 21), max_level=2, max_iters=30, eps=0.01)
     assert np.array_equal(o_st, n_st) and np.array_equal(o_xy.view(np.uint32), np.asarray(n_xy, np.float32).view(np.uint32))
+
+
+def test_fast10_known_answers(O):
+    """FAST-10 by construction: the corner pixel of a bright square on a dark background sees 11 contiguous darker ring
+    pixels (a straight edge sees at most 9), and the bisection score is the contrast minus one"""
+    img = np.full((40, 40), 50, np.uint8)
+    img[10:30, 10:30] = 150
+    sm = O.fast10_score_map(img, 20)
+    corners = {(10, 10), (29, 10), (10, 29), (29, 29)}                      # (x, y) of the square's corner pixels
+    for x, y in corners:
+        assert sm[y, x] == 99, (x, y, sm[y, x])                            # largest b with 10 contiguous < c - b: 150 - 50 - 1
+    assert sm[10, 20] == 0 and sm[20, 10] == 0 and sm[20, 20] == 0          # edges and interior are no corners
+    assert O.fast10_score_map(img, 100)[10, 10] == 0                        # threshold above the contrast: nothing
+    assert (sm[:3] == 0).all() and (sm[:, :3] == 0).all()                   # the detector scans [3, size - 3)
+    # 3x3 non-maximum suppression drops a corner when an adjacent corner scores >= it (ties fall together)
+    m = np.zeros((6, 8), np.uint8); m[2, 2] = 30; m[2, 3] = 30; m[4, 6] = 40; m[3, 5] = 39
+    keep = O.fast_nonmax_3x3(m)
+    assert keep[2, 2] == 0 and keep[2, 3] == 0 and keep[4, 6] == 1 and keep[3, 5] == 0 and keep.sum() == 1
+
+
+def test_check_fundamental_known_answers(O):
+    """CheckFundamental by construction: for a pure x-translation F = [t]_x the epipolar lines are the rows, so matches on the
+    same row have zero residual and each contributes 2 * 5.991; a match 3 rows off (sigma 1: chi2 = 9 > 3.841) contributes nothing"""
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    p1 = np.array([[10, 20], [300, 45], [77, 199], [5, 5]], np.float32)
+    p2 = p1 + np.array([[7, 0], [-3, 0], [12, 0], [4, 3]], np.float32)
+    score, inl = O.check_fundamental(F, p1, p2, 1.0)
+    assert inl.tolist() == [1, 1, 1, 0]
+    assert score == np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991)
+    score3, inl3 = O.check_fundamental(F, p1, p2, 3.0)                      # sigma 3: chi2 = 1 on both sides -> inlier, 2 * (5.991 - 1)
+    assert inl3.tolist() == [1, 1, 1, 1] and abs(float(score3) - (6 * 5.991 + 2 * 4.991)) < 1e-4
