@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/hotpath_rows_f.npz: SELF-golden vectors (oracle inputs + outputs, see make_golden.py for why) of the
+rows added around the path -- FAST-10 grid detector, fused panorama paste + normalise, stitch compose, spherical /
+cylindrical pre-warp, CheckFundamental.  Run from the repo root:  python tests/golden/make_golden_rows_f.py"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+synth = importlib.import_module("3dr_amd.synth")
+
+
+def main():
+    out = {}
+    rng = np.random.default_rng(synth.SEED + 7)
+    img = synth.frame_pair(203, 131)[0].astype(np.int16)
+    for _ in range(40):                                     # rectangles: corners on every level
+        x, y = int(rng.integers(0, 190)), int(rng.integers(0, 120))
+        img[y:y + int(rng.integers(3, 30)), x:x + int(rng.integers(3, 30))] += int(rng.integers(-90, 90))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    out["fast_img"] = img
+    out["fast_score_map"] = O.fast10_score_map(img, 20)
+    occ = (np.arange(9 * 6) % 5 == 0).astype(np.uint8)
+    out["fast_occ"] = occ
+    x, y, sc, lv = O.fast_detect_grid(O.halfsample_pyramid(img, 3, O.HALF_REF_X86), 25, 20, 20.0, occ)
+    out["fast_x"], out["fast_y"], out["fast_score"], out["fast_level"] = x, y, sc, lv
+
+    tiles = [np.roll(synth.panorama_tile(120, 80, seed=synth.SEED + i), 9 * i, axis=1) for i in range(3)]
+    Ms = [np.array([[np.cos(a), -np.sin(a), 15 + 70 * i], [np.sin(a), np.cos(a), 12 + 3 * i], [2e-5 * i, -1e-5, 1]], np.float32)
+          for i, a in enumerate((0.02, -0.03, 0.01))]
+    canvas = np.zeros((120, 300, 4), np.float32)
+    for t, M in zip(tiles, Ms):
+        O.panorama_add(t, canvas, M, 18)
+    out["pano_tiles"], out["pano_Ms"] = np.stack(tiles), np.stack(Ms)
+    out["pano_canvas"], out["pano_final"] = canvas, O.normalize_canvas(canvas)
+    out["pano_bbox0"] = np.array(O.panorama_bbox(Ms[0], 120, 80), np.int32)
+    out["pano_ramp"] = O.feather_ramp(3, 60, 18)
+
+    H = np.array([[0.998, -0.03, -52.25], [0.03, 0.998, 5.5], [3e-5, -2e-5, 1]], np.float32)
+    out["stitch_H"] = H
+    Hinv, T, M, size = O.stitch_geometry(H, 120, 80)
+    out["stitch_Hinv"], out["stitch_T"], out["stitch_M"], out["stitch_size"] = Hinv, T, M, np.array(size, np.int32)
+    out["stitch_out"] = O.stitch_compose(tiles[0], tiles[1], H)
+
+    out["sph"] = O.remap(tiles[0], *O.spherical_map(120, 80, 95.5))
+    out["cyl"] = O.remap(tiles[0], *O.cylindrical_map(120, 80, 95.5))
+
+    p1 = np.stack([rng.uniform(5, 115, 200), rng.uniform(5, 75, 200)], 1).astype(np.float32)
+    p2 = (p1 + np.array([6.5, 0.4]) + rng.normal(0, 0.6, p1.shape)).astype(np.float32)
+    Fs = np.stack([np.array([[0, 0, 0.01 * k], [0, 0, -1], [-0.01 * k, 1, 0.3 * k]], np.float32) for k in range(8)])
+    out["cf_p1"], out["cf_p2"], out["cf_F"] = p1, p2, Fs
+    res = [O.check_fundamental(F, p1, p2, 1.5) for F in Fs]
+    out["cf_scores"] = np.array([r[0] for r in res], np.float32)
+    out["cf_inliers"] = np.stack([r[1] for r in res])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hotpath_rows_f.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays;", int((lv >= 0).sum()), "features")
+
+
+if __name__ == "__main__":
+    main()

@@ -66,3 +66,59 @@ def test_hip_reproduces_golden(dr3, ctx):
     for name, mode in (("trunc", dr3.HALF_TRUNC), ("sse2", dr3.HALF_SSE2), ("refscalar", dr3.HALF_REF_SCALAR), ("refx86", dr3.HALF_REF_X86)):
         assert np.array_equal(ctx.create_img_pyramid(G["half_src_odd"], 2, mode)[1], G["half_odd_" + name])
         assert np.array_equal(ctx.create_img_pyramid(G["half_src_16"], 2, mode)[1], G["half_16_" + name])
+
+
+F = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_rows_f.npz"))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_oracle_reproduces_golden_rows_f(O):
+    """the rows around the path (tests/golden/hotpath_rows_f.npz, made by make_golden_rows_f.py)"""
+    img = F["fast_img"]
+    assert np.array_equal(O.fast10_score_map(img, 20), F["fast_score_map"])
+    x, y, sc, lv = O.fast_detect_grid(O.halfsample_pyramid(img, 3, O.HALF_REF_X86), 25, 20, 20.0, F["fast_occ"])
+    assert np.array_equal(lv, F["fast_level"]) and np.array_equal(x, F["fast_x"]) and np.array_equal(y, F["fast_y"])
+    assert np.array_equal(_bits(sc), _bits(F["fast_score"]))
+    canvas = np.zeros((120, 300, 4), np.float32)
+    for t, M in zip(F["pano_tiles"], F["pano_Ms"]):
+        O.panorama_add(t, canvas, M, 18)
+    assert np.array_equal(_bits(canvas), _bits(F["pano_canvas"])) and np.array_equal(O.normalize_canvas(canvas), F["pano_final"])
+    assert tuple(F["pano_bbox0"]) == O.panorama_bbox(F["pano_Ms"][0], 120, 80)
+    assert np.array_equal(_bits(O.feather_ramp(3, 60, 18)), _bits(F["pano_ramp"]))
+    Hinv, T, M, size = O.stitch_geometry(F["stitch_H"], 120, 80)
+    assert size == tuple(F["stitch_size"]) and np.array_equal(_bits(Hinv), _bits(F["stitch_Hinv"])) and np.array_equal(_bits(M), _bits(F["stitch_M"]))
+    assert np.array_equal(O.stitch_compose(F["pano_tiles"][0], F["pano_tiles"][1], F["stitch_H"]), F["stitch_out"])
+    assert np.array_equal(O.remap(F["pano_tiles"][0], *O.spherical_map(120, 80, 95.5)), F["sph"])
+    assert np.array_equal(O.remap(F["pano_tiles"][0], *O.cylindrical_map(120, 80, 95.5)), F["cyl"])
+    for k, Fk in enumerate(F["cf_F"]):
+        s, inl = O.check_fundamental(Fk, F["cf_p1"], F["cf_p2"], 1.5)
+        assert s.view(np.uint32) == F["cf_scores"][k].view(np.uint32) and np.array_equal(inl, F["cf_inliers"][k])
+
+
+def test_host_geometry_reproduces_golden_rows_f(dr3):
+    """the host-only entry points of the C ABI need no GPU"""
+    assert dr3.panorama_bbox(F["pano_Ms"][0], 120, 80) == tuple(F["pano_bbox0"])
+    assert np.array_equal(_bits(dr3.panorama_ramp(3, 60, 18)), _bits(F["pano_ramp"]))
+    Hinv, T, M, size = dr3.stitch_geometry(F["stitch_H"], 120, 80)
+    assert size == tuple(F["stitch_size"]) and np.array_equal(_bits(Hinv), _bits(F["stitch_Hinv"]))
+    assert np.array_equal(_bits(T), _bits(F["stitch_T"])) and np.array_equal(_bits(M), _bits(F["stitch_M"]))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_rows_f(dr3, ctx):
+    img = F["fast_img"]
+    assert np.array_equal(ctx.fast_score_map(img, 20), F["fast_score_map"])
+    x, y, sc, lv = ctx.fast_detect(img, 3, 25, 20, 20.0, F["fast_occ"])
+    m = F["fast_level"] >= 0
+    assert np.array_equal(lv, F["fast_level"]) and np.array_equal(x[m], F["fast_x"][m]) and np.array_equal(y[m], F["fast_y"][m])
+    assert np.array_equal(_bits(sc[m]), _bits(F["fast_score"][m]))
+    canvas, final = ctx.paste_images(list(F["pano_tiles"]), list(F["pano_Ms"]), (300, 120), 18)
+    assert np.array_equal(_bits(canvas), _bits(F["pano_canvas"])) and np.array_equal(final, F["pano_final"])
+    assert np.array_equal(ctx.stitch_compose(F["pano_tiles"][0], F["pano_tiles"][1], F["stitch_H"]), F["stitch_out"])
+    assert np.array_equal(ctx.warp_spherical(F["pano_tiles"][0], 95.5), F["sph"])
+    assert np.array_equal(ctx.warp_cylindrical(F["pano_tiles"][0], 95.5), F["cyl"])
+    scores, inl = ctx.check_fundamental(F["cf_F"], F["cf_p1"], F["cf_p2"], 1.5)
+    assert np.array_equal(_bits(scores), _bits(F["cf_scores"])) and np.array_equal(inl, F["cf_inliers"])
