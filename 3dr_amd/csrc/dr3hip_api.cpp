@@ -888,9 +888,8 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
         v.w = lw; v.h = lh;
         // levels >= 1 carry OpenCV's winSize border physically (lk_kernels.hip): wide enough for the template window,
         // the staged search region (window + 4 px margin) and their dword alignment slop
-        const bool no_pad = getenv("DR3HIP_DBG_NO_PAD") != nullptr;
-        v.pad_x = (l && !no_pad) ? align_up(win_w + 16, 4) : 0;
-        v.pad_y = (l && !no_pad) ? win_h + 6 : 0;
+        v.pad_x = l ? align_up(win_w + 16, 4) : 0;
+        v.pad_y = l ? win_h + 6 : 0;
         v.pitch = align_up(lw + 2 * v.pad_x + 8, 64);
         v.dpitch = align_up(4 * (lw + 2 * v.pad_x) + 16, 128);
         const int rows = lh + 2 * v.pad_y;
