@@ -12,9 +12,11 @@
 //      per level instead of one per Gauss-Newton iteration;
 //   2. extracts its taps of the template patch (I, Ix, Iy: 14-bit fixed-point bilinear, integer
 //      exact) once and keeps them in registers;
-//   3. iterates out of LDS: two ds_read2_b32 per lane-item, v_perm_b32 + v_dot2_u32_u16 for the
-//      bilinear J taps, v_mul_i32_i24 for mismatch x gradient, f32 accumulation;
-//   4. reduces the two f32 sums across the wave with one v_permlane32_swap + DPP adds (no LDS),
+//   3. iterates out of LDS: two ds_read2_b32 per lane-item, v_perm_b32 + v_dot2_i32_i16 for the
+//      bilinear J taps (the template value rides in the dot's accumulator, so the dot yields the
+//      mismatch directly), mismatches packed in int16 pairs and multiplied onto the packed
+//      gradients with v_dot2_i32_i16 again: 6.5 VALU per tap;
+//   4. reduces the two sums across the wave with one v_permlane32_swap + DPP adds (no LDS),
 //      solves the 2x2 system redundantly in every lane and tests the wave-uniform exit conditions.
 // If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged
 // around it, so results never depend on the margin.
@@ -24,8 +26,10 @@
 // border physically (LevelDev::pad_x / pad_y, written by pad_reflect_kernel), because a third of the
 // windows cross the image edge there and the reflecting paths cost 15 % of this kernel.
 //
-// Float summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64):
-// lane-local sequential over (pass, tap k) into p[lane]; a[l] = p[l] + p[l+32] (l < 32); inside
+// Summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64): every term is an
+// integer; the taps of one lane are summed exactly in int32 (<= 16 taps of < 2^25.1) and converted
+// to f32 once into p[lane] (OpenCV converts every term and rounds at every add: the kernel's sum is
+// the more accurate one, tests bound the difference); a[l] = p[l] + p[l+32] (l < 32); inside
 // each row of 16 lanes an xor butterfly with strides 1,2,4,8 gives the row sums R0, R1; the total
 // is R1 + R0.  wave_sum2 produces exactly that tree for TWO sums at once.  No FMA contraction
 // (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
@@ -93,16 +97,29 @@ __device__ __forceinline__ uint32_t tap_sel(int o, int k)
     return 0x0c000c00u | (uint32_t)(o + k) | ((uint32_t)(o + k + 1) << 16);
 }
 
-// CV_DESCALE(I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11, W_BITS - 5): two perms + two dot2
-__device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weights& W)
+// (I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11 + acc) >> (W_BITS - 5): two perms + two dot2.
+// acc = BILIN_ROUND gives CV_DESCALE(..., W_BITS - 5); acc = BILIN_ROUND - (t << (W_BITS - 5)) gives that minus t
+// (the subtrahend is a multiple of the shift's divisor, so floor commutes with it).
+constexpr int BILIN_ROUND = 1 << (W_BITS - 5 - 1);
+__device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weights& W, int acc)
 {
     const uint32_t p0 = __builtin_amdgcn_perm(r.hi0, r.lo0, sel);
     const uint32_t p1 = __builtin_amdgcn_perm(r.hi1, r.lo1, sel);
     // signed dot: iw11 = 2^14 - iw00 - iw01 - iw10 is -1 or -2 when both fractions are a few 1e-5 (the three rounded
     // weights then sum to more than 2^14); OpenCV carries it as a negative int, so must the packed 16-bit lane
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 5 - 1), false);
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), acc, false);
     v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, false);
     return v >> (W_BITS - 5);
+}
+
+// (lo | hi << 16) of two values that fit int16
+__device__ __forceinline__ uint32_t pack_s16(int lo, int hi)
+{
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+__device__ __forceinline__ int dot_s16(uint32_t a, uint32_t b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, false);
 }
 
 // CV_DESCALE(d00*iw00 + d01*iw01 + d10*iw10 + d11*iw11, W_BITS) on one int16 channel of the
@@ -223,8 +240,10 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
     int   status = 1;
     float err = 0.f;
 
-    // template patch of this lane: I (x32), Ix, Iy per tap
-    int Iv[NPASS][4], Ix[NPASS][4], Iy[NPASS][4];
+    // template patch of this lane: per tap the dot accumulator BILIN_ROUND - (I << 9); Ix, Iy as int16 pairs of taps
+    // (0,1) and (2,3), zero on the taps beyond the window's last column
+    int Ib[NPASS][4];
+    uint32_t Ix[NPASS][2], Iy[NPASS][2];
 
     for (int level = a.max_level; level >= 0; --level) {
         const LevelDev L = a.lv[level];
@@ -274,11 +293,12 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             const bool inside = L.pad_x > 0 || (ipx >= 0 && ipy >= 0 && ipx + win_w < L.w && ipy + win_h < L.h);
             const int o = inside ? (ipx & 3) : 0;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
-            float s11 = 0.f, s12 = 0.f, s22 = 0.f;
+            int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { Iv[p][k] = 0; Ix[p][k] = 0; Iy[p][k] = 0; }
+                for (int k = 0; k < 4; ++k) Ib[p][k] = 0;
+                Ix[p][0] = Ix[p][1] = Iy[p][0] = Iy[p][1] = 0u;
                 if (ivalid[p]) {
                     const int x = ipx + itx[p], y = ipy + ity[p];
                     Rows r;
@@ -302,24 +322,31 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
                             d1[k] = (okx && v1) ? q1[xx] : 0u;
                         }
                     }
+                    int gx[4], gy[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        gx[k] = 0; gy[k] = 0;
                         if (itx[p] + k < win_w) {
                             const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
-                            const int ival  = bilin_u8(r, sel, W);
-                            const int ixval = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
-                            const int iyval = bilin_s16<0x07060302u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
-                            Iv[p][k] = ival; Ix[p][k] = ixval; Iy[p][k] = iyval;
-                            s11 += (float)__mul24(ixval, ixval);
-                            s12 += (float)__mul24(ixval, iyval);
-                            s22 += (float)__mul24(iyval, iyval);
+                            Ib[p][k] = BILIN_ROUND - (bilin_u8(r, sel, W, BILIN_ROUND) << (W_BITS - 5));
+                            gx[k] = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
+                            gy[k] = bilin_s16<0x07060302u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
                         }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t x2 = pack_s16(gx[2 * h], gx[2 * h + 1]), y2 = pack_s16(gy[2 * h], gy[2 * h + 1]);
+                        Ix[p][h] = x2; Iy[p][h] = y2;
+                        s11 = dot_s16(x2, x2, s11);
+                        s12 = dot_s16(x2, y2, s12);
+                        s22 = dot_s16(y2, y2, s22);
                     }
                 }
             }
             float unused;
-            wave_sum2(s11, s12, A11, A12);
-            wave_sum2(s22, s22, A22, unused);
+            const float f22 = (float)s22;
+            wave_sum2((float)s11, (float)s12, A11, A12);
+            wave_sum2(f22, f22, A22, unused);
             A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
 
@@ -352,23 +379,20 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             const int o = inx & 3;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
             const int base = (iny - R.y0) * lpd + (((inx & ~3) - R.x0) >> 2);
-            float s1 = 0.f, s2 = 0.f;
+            int s1 = 0, s2 = 0;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 if (ivalid[p]) {
                     const Rows r = lds_rows(lds, lpd, base, loff[p]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        // masked taps carry Ix = Iy = 0: their terms are +0.0f, an exact no-op
-                        const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
-                        const int diff = bilin_u8(r, sel, W) - Iv[p][k];
-                        s1 += (float)__mul24(diff, Ix[p][k]);
-                        s2 += (float)__mul24(diff, Iy[p][k]);
-                    }
+                    // taps beyond the window's last column carry Ix = Iy = 0: whatever mismatch they see adds nothing
+                    const uint32_t m01 = pack_s16(bilin_u8(r, sel0, W, Ib[p][0]), bilin_u8(r, sel1, W, Ib[p][1]));
+                    const uint32_t m23 = pack_s16(bilin_u8(r, sel2, W, Ib[p][2]), bilin_u8(r, sel3, W, Ib[p][3]));
+                    s1 = dot_s16(m01, Ix[p][0], s1); s1 = dot_s16(m23, Ix[p][1], s1);
+                    s2 = dot_s16(m01, Iy[p][0], s2); s2 = dot_s16(m23, Iy[p][1], s2);
                 }
             }
             float b1, b2;
-            wave_sum2(s1, s2, b1, b2);
+            wave_sum2((float)s1, (float)s2, b1, b2);
             b1 *= FLT_SCALE; b2 *= FLT_SCALE;
 
             const float dx = (A12 * b2 - A22 * b1) * D;
@@ -411,8 +435,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
                     for (int k = 0; k < 4; ++k) {
                         if (itx[p] + k < win_w) {
                             const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
-                            const int diff = bilin_u8(r, sel, W) - Iv[p][k];
-                            se += fabsf((float)diff);
+                            se += fabsf((float)bilin_u8(r, sel, W, Ib[p][k]));      // exact: 16 taps of <= 2^13
                         }
                     }
                 }

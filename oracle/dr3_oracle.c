@@ -158,7 +158,7 @@ static inline int der_at(const lvl_deriv* D, int x, int y, int c)
 typedef struct {
     int   order;
     int   win_w, rpr;             /* runs per row for WAVE64 */
-    float lane[3][64];            /* up to three simultaneous sums */
+    long long lane[3][64];        /* up to three simultaneous sums: the lane-local part is an exact integer sum */
     float acc[3];
 } wsum;
 
@@ -168,11 +168,14 @@ static void wsum_init(wsum* s, int order, int win_w)
     memset(s->lane, 0, sizeof(s->lane));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
 }
-/* WAVE64 order: lane-item q = ty*rpr + (tx/4); pass = q/64, lane = q%64.  Because the caller
- * walks taps in raster order, for a fixed lane the sequence (pass asc, k asc) is preserved. */
-static inline void wsum_add(wsum* s, int which, int tx, int ty, float v)
+/* Every term of the three LK window sums is an integer (a product of two fixed-point values, or |diff|).
+ * RASTER (OpenCV's scalar path): converted to f32 and added in raster order, each add rounding.
+ * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx/4); pass = q/64, lane = q%64; the taps of one lane are summed
+ * as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so int32 cannot overflow in the
+ * kernel), converted to f32 once, and the 64 lane values go through the f32 tree of wsum_get. */
+static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)
 {
-    if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += v; return; }
+    if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += (float)v; return; }
     {
         const int q = ty * s->rpr + (tx >> 2);
         s->lane[which][q & 63] += v;
@@ -186,7 +189,7 @@ static float wsum_get(wsum* s, int which)
          * onto the lower, xor butterfly 1,2,4,8 inside each row of 16 lanes, then R1 + R0 */
         float a[32], b[32];
         int off, l;
-        for (l = 0; l < 32; ++l) a[l] = s->lane[which][l] + s->lane[which][l + 32];
+        for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
         for (off = 1; off < 16; off <<= 1) {
             for (l = 0; l < 32; ++l) b[l] = a[l] + a[l ^ off];
             memcpy(a, b, sizeof(a));
@@ -195,10 +198,6 @@ static float wsum_get(wsum* s, int which)
     }
 }
 
-/* NOTE on WAVE64 and pass ordering: a lane that owns items in several passes adds them in pass
- * order (pass 0's four taps, then pass 1's...).  Raster order visits (ty asc, tx asc); item q is
- * monotone in (ty, tx>>2), so for one lane q, q+64, q+128 ... are visited in ascending order and
- * the taps of one item in ascending k.  Hence wsum_add above reproduces the kernel's order. */
 
 static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* dI,
                            int max_level, const float* prev_pt, float* next_pt,
@@ -269,9 +268,9 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
                 Ibuf[y * win_w + x] = (int16_t)ival;
                 dIbuf[2 * (y * win_w + x)]     = (int16_t)ixval;
                 dIbuf[2 * (y * win_w + x) + 1] = (int16_t)iyval;
-                wsum_add(&S, 0, x, y, (float)(ixval * ixval));
-                wsum_add(&S, 1, x, y, (float)(ixval * iyval));
-                wsum_add(&S, 2, x, y, (float)(iyval * iyval));
+                wsum_add(&S, 0, x, y, ixval * ixval);
+                wsum_add(&S, 1, x, y, ixval * iyval);
+                wsum_add(&S, 2, x, y, iyval * iyval);
             }
         }
         A11 = wsum_get(&S, 0) * FLT_SCALE;
@@ -315,8 +314,8 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
                     const int diff = DESCALE(img_at(Jl, X, Y) * iw00 + img_at(Jl, X + 1, Y) * iw01 +
                                              img_at(Jl, X, Y + 1) * iw10 + img_at(Jl, X + 1, Y + 1) * iw11,
                                              W_BITS - 5) - Ibuf[y * win_w + x];
-                    wsum_add(&S, 0, x, y, (float)(diff * dIbuf[2 * (y * win_w + x)]));
-                    wsum_add(&S, 1, x, y, (float)(diff * dIbuf[2 * (y * win_w + x) + 1]));
+                    wsum_add(&S, 0, x, y, diff * dIbuf[2 * (y * win_w + x)]);
+                    wsum_add(&S, 1, x, y, diff * dIbuf[2 * (y * win_w + x) + 1]);
                 }
             }
             b1 = wsum_get(&S, 0) * FLT_SCALE;
@@ -359,7 +358,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
                     const int diff = DESCALE(img_at(Jl, X, Y) * iw00 + img_at(Jl, X + 1, Y) * iw01 +
                                              img_at(Jl, X, Y + 1) * iw10 + img_at(Jl, X + 1, Y + 1) * iw11,
                                              W_BITS - 5) - Ibuf[y * win_w + x];
-                    wsum_add(&S, 0, x, y, fabsf((float)diff));
+                    wsum_add(&S, 0, x, y, diff < 0 ? -diff : diff);
                 }
             }
             errval = wsum_get(&S, 0);
