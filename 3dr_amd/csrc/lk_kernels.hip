@@ -76,15 +76,21 @@ __device__ __forceinline__ void wave_sum2(float a, float b, float& ra, float& rb
 // 14-bit weights packed for the dot2 instructions: (w00 | w01 << 16), (w10 | w11 << 16)
 struct Weights { uint32_t w01, w23; };
 
+// cvRound(x * 2^14) of the three products, the fourth as the remainder.  Scaling one factor by 2^14 first gives the
+// same bits as scaling the product (power of two, no under/overflow here).  Rounding: x + 1.5 * 2^23 rounds to
+// nearest-even exactly like cvRound for 0 <= x <= 2^14 and leaves the integer in the low bits of the float's
+// pattern (0x4B400000 + n), so the int16 halves are picked straight out of the patterns.
 __device__ __forceinline__ Weights make_weights(float a, float b)
 {
-    const int w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    const int w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
-    const int w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
-    const int w11 = (1 << W_BITS) - w00 - w01 - w10;
+    const float MAGIC = 12582912.f;             // 1.5 * 2^23, pattern 0x4B400000
+    const float na = (1.f - a) * (float)(1 << W_BITS), sa = a * (float)(1 << W_BITS), nb = 1.f - b;
+    const uint32_t t00 = __float_as_uint(na * nb + MAGIC);
+    const uint32_t t01 = __float_as_uint(sa * nb + MAGIC);
+    const uint32_t t10 = __float_as_uint(na * b + MAGIC);
+    const uint32_t w11 = (uint32_t)(1 << W_BITS) + 3u * 0x4B400000u - (t00 + t01 + t10);     // may be -1 or -2
     Weights W;
-    W.w01 = (uint32_t)w00 | ((uint32_t)w01 << 16);
-    W.w23 = (uint32_t)w10 | ((uint32_t)w11 << 16);
+    W.w01 = __builtin_amdgcn_perm(t01, t00, 0x05040100u);
+    W.w23 = __builtin_amdgcn_perm(w11, t10, 0x05040100u);
     return W;
 }
 
@@ -101,14 +107,18 @@ __device__ __forceinline__ uint32_t tap_sel(int o, int k)
 // acc = BILIN_ROUND gives CV_DESCALE(..., W_BITS - 5); acc = BILIN_ROUND - (t << (W_BITS - 5)) gives that minus t
 // (the subtrahend is a multiple of the shift's divisor, so floor commutes with it).
 constexpr int BILIN_ROUND = 1 << (W_BITS - 5 - 1);
+// The saturating form of v_dot2_i32_i16 is the three-operand encoding: the accumulator is a free source instead of
+// being tied to the destination (the non-saturating builtin selects v_dot2c and a v_mov per use).  No sum here can
+// reach the int32 limits (bilinear: < 2^31 / 64; window sums: <= 16 taps of < 2^25.1), so saturation never acts.
+constexpr bool DOT_SAT = true;
 __device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weights& W, int acc)
 {
     const uint32_t p0 = __builtin_amdgcn_perm(r.hi0, r.lo0, sel);
     const uint32_t p1 = __builtin_amdgcn_perm(r.hi1, r.lo1, sel);
     // signed dot: iw11 = 2^14 - iw00 - iw01 - iw10 is -1 or -2 when both fractions are a few 1e-5 (the three rounded
     // weights then sum to more than 2^14); OpenCV carries it as a negative int, so must the packed 16-bit lane
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), acc, false);
-    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, false);
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), acc, DOT_SAT);
+    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, DOT_SAT);
     return v >> (W_BITS - 5);
 }
 
@@ -119,7 +129,7 @@ __device__ __forceinline__ uint32_t pack_s16(int lo, int hi)
 }
 __device__ __forceinline__ int dot_s16(uint32_t a, uint32_t b, int acc)
 {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, false);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, DOT_SAT);
 }
 
 // CV_DESCALE(d00*iw00 + d01*iw01 + d10*iw10 + d11*iw11, W_BITS) on one int16 channel of the
@@ -129,8 +139,8 @@ __device__ __forceinline__ int bilin_s16(uint32_t a0, uint32_t a1, uint32_t b0, 
 {
     const uint32_t p0 = __builtin_amdgcn_perm(a1, a0, SEL);
     const uint32_t p1 = __builtin_amdgcn_perm(b1, b0, SEL);
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 1), false);
-    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, false);
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 1), DOT_SAT);
+    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, DOT_SAT);
     return v >> W_BITS;
 }
 
@@ -366,8 +376,10 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
         // ---- Gauss-Newton iterations (out of LDS) -----------------------------------------------
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; ++j) {
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cx));
-            const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cy));
+            // the floors stay floats for the fractions: (float)inx == fcx whenever the bounds test lets the point through
+            const float fcx = floorf(cx), fcy = floorf(cy);
+            const int inx = __builtin_amdgcn_readfirstlane((int)fcx);
+            const int iny = __builtin_amdgcn_readfirstlane((int)fcy);
             if (inx < -win_w || inx >= L.w || iny < -win_h || iny >= L.h) {
                 if (level == 0) status = 0;
                 break;
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
             it_count = j + 1;
             if (!region_covers(R, inx, iny, rpr, win_h, rwd, rh))
                 R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, a.cw_shift, lane);
-            const Weights W = make_weights(cx - (float)inx, cy - (float)iny);
+            const Weights W = make_weights(cx - fcx, cy - fcy);
             const int o = inx & 3;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
             const int base = (iny - R.y0) * lpd + (((inx & ~3) - R.x0) >> 2);
