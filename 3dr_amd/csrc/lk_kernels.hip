@@ -217,7 +217,8 @@ __device__ __forceinline__ Rows lds_rows(const uint32_t* __restrict__ lds, int l
 }
 
 template <int NPASS>
-__global__ __launch_bounds__(64) void lk_track_kernel(const LKArgs a)
+// 15x15-class windows (one pass): 8 waves per SIMD need <= 96 SGPRs; the compiler parks the excess in VGPR lanes
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ? 8 : 4))) void lk_track_kernel(const LKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
