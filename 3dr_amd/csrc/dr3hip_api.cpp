@@ -1018,6 +1018,7 @@ static int fill_lk_args(dr3hip_batch* b, const dr3hip_lk_params* p, LKArgs& a)
     a.max_level = L;
     a.win_w = p->win_w; a.win_h = p->win_h;
     a.rpr = (p->win_w + 3) / 4;
+    a.rpr_magic = (65536 + a.rpr - 1) / a.rpr;
     a.n_items = a.rpr * p->win_h;
     // staged J search region (lk_kernels.hip): window + one alignment dword + 4 px margin each side
     a.rwd = a.rpr + 3;

@@ -29,10 +29,10 @@
 // Summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64): every term is an
 // integer; the taps of one lane are summed exactly in int32 (<= 16 taps of < 2^25.1) and converted
 // to f32 once into p[lane] (OpenCV converts every term and rounds at every add: the kernel's sum is
-// the more accurate one, tests bound the difference); a[l] = p[l] + p[l+32] (l < 32); inside
-// each row of 16 lanes an xor butterfly with strides 1,2,4,8 gives the row sums R0, R1; the total
-// is R1 + R0.  wave_sum2 produces exactly that tree for TWO sums at once.  No FMA contraction
-// (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
+// the more accurate one, tests bound the difference); a[l] = p[l] + p[l+32] (l < 32);
+// c[l] = a[l] + a[l+16] (l < 16); an xor butterfly with strides 1,2,4,8 over the 16 values gives the
+// total.  wave_sum2 / wave_sum3 produce exactly that tree for two / three sums at once.  No FMA
+// contraction (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
 #include "dr3hip_internal.h"
 
 namespace dr3 {
@@ -50,26 +50,49 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// ---- wave64 reduction of two f32 sums at once ---------------------------------------------------
+// ---- wave64 reductions of several f32 sums at once ----------------------------------------------
+// One tree for every sum: fold the upper half-wave onto the lower (v_permlane32_swap), fold the odd rows of 16 lanes
+// onto the even ones (v_permlane16_swap), xor butterfly 1,2,4,8 inside the row.  The swaps move two (four) different
+// sums into disjoint rows, so one butterfly finishes all of them.
 template <int CTRL>
 __device__ __forceinline__ float dpp_xchg(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-
-__device__ __forceinline__ void wave_sum2(float a, float b, float& ra, float& rb)
+// lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
+__device__ __forceinline__ float fold32(float a, float b)
 {
-    // lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+// rows (R0 R1 R2 R3) of u and w  ->  (u.R0 + u.R1, w.R0 + w.R1, u.R2 + u.R3, w.R2 + w.R3)
+__device__ __forceinline__ float fold16(float u, float w)
+{
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ float row_butterfly(float v)
+{
     v += dpp_xchg<0xB1>(v);     // quad_perm [1,0,3,2]   (xor 1)
     v += dpp_xchg<0x4E>(v);     // quad_perm [2,3,0,1]   (xor 2)
     v += dpp_xchg<0x141>(v);    // row_half_mirror       (= xor 4 once quads are uniform)
     v += dpp_xchg<0x140>(v);    // row_mirror            (= xor 8 once half-rows are uniform)
-    // rows 1 and 3 += last lane of rows 0 and 2 (masked rows read old = 0)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
-    ra = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-    rb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return v;
+}
+__device__ __forceinline__ float lane_value(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ void wave_sum2(float a, float b, float& ra, float& rb)
+{
+    const float u = fold32(a, b);
+    const float v = row_butterfly(fold16(u, u));           // rows: a a b b
+    ra = lane_value(v, 0); rb = lane_value(v, 32);
+}
+__device__ __forceinline__ void wave_sum3(float a, float b, float c, float& ra, float& rb, float& rc)
+{
+    const float v = row_butterfly(fold16(fold32(a, b), fold32(c, c)));      // rows: a c b c
+    ra = lane_value(v, 0); rb = lane_value(v, 32); rc = lane_value(v, 16);
 }
 
 // ---- fixed-point bilinear blends ------------------------------------------------------------------
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
     for (int p = 0; p < NPASS; ++p) {
         const int q = p * 64 + lane;
         ivalid[p] = q < a.n_items;
-        ity[p] = q / rpr;
+        ity[p] = (int)(__umul24((unsigned)q, (unsigned)a.rpr_magic) >> 16);     // q / rpr (host-made reciprocal)
         itx[p] = 4 * (q - ity[p] * rpr);
         loff[p] = ity[p] * lpd + (itx[p] >> 2);
     }
@@ -354,10 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
                     }
                 }
             }
-            float unused;
-            const float f22 = (float)s22;
-            wave_sum2((float)s11, (float)s12, A11, A12);
-            wave_sum2(f22, f22, A22, unused);
+            wave_sum3((float)s11, (float)s12, (float)s22, A11, A12, A22);
             A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
         }
 

@@ -185,16 +185,17 @@ static float wsum_get(wsum* s, int which)
 {
     if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
     {
-        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2): fold the upper half-wave
-         * onto the lower, xor butterfly 1,2,4,8 inside each row of 16 lanes, then R1 + R0 */
-        float a[32], b[32];
+        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3): fold the upper half-wave
+         * onto the lower, the upper 16 of those onto the lower 16, then an xor butterfly 1,2,4,8 */
+        float a[32], c[16], b[16];
         int off, l;
         for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
+        for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
         for (off = 1; off < 16; off <<= 1) {
-            for (l = 0; l < 32; ++l) b[l] = a[l] + a[l ^ off];
-            memcpy(a, b, sizeof(a));
+            for (l = 0; l < 16; ++l) b[l] = c[l] + c[l ^ off];
+            memcpy(c, b, sizeof(c));
         }
-        return a[16] + a[0];
+        return c[0];
     }
 }
 
