@@ -44,6 +44,14 @@ constexpr int RM = 4;              // search margin (px) of the staged J region
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// cvFloor as the reference's x86 build computes it for the bounds tests: cvttss2si yields INT_MIN for NaN, so a NaN
+// coordinate is "outside" (status 0), where a plain float->int conversion would give 0 and let it through.
+// v_med3_f32 returns the smaller bound when an operand is NaN; the conversion then saturates to INT_MIN.
+__device__ __forceinline__ int floor_to_int(float floored)
+{
+    return (int)__builtin_amdgcn_fmed3f(floored, -3.0e9f, 3.0e9f);
+}
+
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         int it_count = 0;
 
         px -= half_x; py -= half_y;
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px));
-        const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
+        const int ipx = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(px)));
+        const int ipy = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(py)));
 
         if (ipx < -win_w || ipx >= L.w || ipy < -win_h || ipy >= L.h) {
             if (level == 0) { status = 0; err = 0.f; }
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         for (int j = 0; j < a.max_count; ++j) {
             // the floors stay floats for the fractions: (float)inx == fcx whenever the bounds test lets the point through
             const float fcx = floorf(cx), fcy = floorf(cy);
-            const int inx = __builtin_amdgcn_readfirstlane((int)fcx);
-            const int iny = __builtin_amdgcn_readfirstlane((int)fcy);
+            const int inx = __builtin_amdgcn_readfirstlane(floor_to_int(fcx));
+            const int iny = __builtin_amdgcn_readfirstlane(floor_to_int(fcy));
             if (inx < -win_w || inx >= L.w || iny < -win_h || iny >= L.h) {
                 if (level == 0) status = 0;
                 break;
@@ -447,8 +455,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         // ---- residual (level 0 only) -------------------------------------------------------------
         if (status && level == 0 && !(a.flags & DR3HIP_LK_GET_MIN_EIGENVALS)) {
             const float fx = nx - half_x, fy = ny - half_y;
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(fx));
-            const int iny = __builtin_amdgcn_readfirstlane((int)floorf(fy));
+            const int inx = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(fx)));
+            const int iny = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(fy)));
             if (inx < -win_w || inx >= L.w || iny < -win_h || iny >= L.h) {
                 status = 0;
                 continue;

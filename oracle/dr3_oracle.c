@@ -36,7 +36,10 @@ static inline int reflect101(int p, int len)
  * 0x80000000 for NaN, infinities and anything outside the int range (a 64-bit lrint would wrap instead). */
 static inline int cv_round_f(float v)  { return (v >= -2147483648.f && v < 2147483648.f) ? (int)lrintf(v) : (int)0x80000000; }
 static inline int cv_round_d(double v) { return (v >= -2147483648.0 && v < 2147483647.5) ? (int)lrint(v) : (int)0x80000000; }
-static inline int cv_floor_f(float v)  { return (int)floorf(v); }
+/* cvFloor(float) = (int)v adjusted downwards; (int)v is cvttss2si: INT_MIN for NaN and for anything outside the int range.
+ * (For v < -2^31 the adjustment wraps INT_MIN to INT_MAX in the reference's build; either value fails every bounds test
+ * that consumes it, which is all LK does with it, so the indefinite value is returned as is.) */
+static inline int cv_floor_f(float v)  { return (v >= -2147483648.f && v < 2147483648.f) ? (int)floorf(v) : (int)0x80000000; }
 
 static inline short sat_s16(int v)
 {

@@ -153,6 +153,35 @@ def test_points_on_and_beyond_borders(dr3, O, synth, ctx):
     assert g_st[10] == 0                      # far outside: lost
 
 
+def test_non_finite_points_follow_x86_cvfloor(dr3, O, synth, ctx):
+    """NaN / inf / out-of-int-range coordinates: the reference's cvFloor is cvttss2si, INT_MIN for all of them, so such a
+    point fails the bounds test (status 0, err 0) -- as a previous point and as a USE_INITIAL_FLOW guess"""
+    A, B, _ = synth.frame_pair(320, 200)
+    pts = synth.grid_points(320, 200, 24, border=10)[:64].copy()
+    bad = np.array([np.nan, np.inf, -np.inf, 3e9, -3e9, 1e20, -1e20, 2147483520.0], np.float32)
+    for i, v in enumerate(bad):
+        pts[2 * i, 0] = v
+        pts[2 * i + 1, 1] = v
+    pg, po = _params(dr3, O, win=(15, 15), max_level=3, max_iters=30, eps=0.01, flags=0)
+    g_xy, g_st, g_err, _ = ctx.calcOpticalFlowPyrLK(A, B, pts, None, pg)
+    o_xy, o_st, o_err, _ = O.lk_track(A, B, pts, None, po, order=O.ORDER_WAVE64)
+    assert np.array_equal(g_st, o_st) and not g_st[:2 * len(bad)].any() and g_st[2 * len(bad):].all()
+    assert np.array_equal(g_err.view(np.uint32), o_err.view(np.uint32))
+    assert np.array_equal(g_xy, o_xy, equal_nan=True)
+    # the same values as initial guesses of good points
+    good = synth.grid_points(320, 200, 24, border=10)[:64].copy()
+    guess = good.copy()
+    for i, v in enumerate(bad):
+        guess[2 * i, 0] = v
+        guess[2 * i + 1, 1] = v
+    pg, po = _params(dr3, O, win=(15, 15), max_level=3, max_iters=30, eps=0.01, flags=dr3.LK_USE_INITIAL_FLOW)
+    g_xy, g_st, g_err, _ = ctx.calcOpticalFlowPyrLK(A, B, good, guess, pg)
+    o_xy, o_st, o_err, _ = O.lk_track(A, B, good, guess, po, order=O.ORDER_WAVE64)
+    assert np.array_equal(g_st, o_st) and not g_st[:2 * len(bad)].any()
+    assert np.array_equal(g_err.view(np.uint32), o_err.view(np.uint32))
+    assert np.array_equal(g_xy, o_xy, equal_nan=True)
+
+
 def test_negative_fourth_bilinear_weight(dr3, O, synth, ctx):
     """iw11 = 2^14 - iw00 - iw01 - iw10 is -1 when both sub-pixel fractions are a few 1e-5 (the three rounded weights sum to
     2^14 + 1); OpenCV carries it as a negative int.  Regression: the kernel once packed it into an UNSIGNED 16-bit dot lane,

@@ -252,3 +252,15 @@ def test_check_fundamental_known_answers(O):
     assert score == np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991) + np.float32(5.991)
     score3, inl3 = O.check_fundamental(F, p1, p2, 3.0)                      # sigma 3: chi2 = 1 on both sides -> inlier, 2 * (5.991 - 1)
     assert inl3.tolist() == [1, 1, 1, 1] and abs(float(score3) - (6 * 5.991 + 2 * 4.991)) < 1e-4
+
+
+def test_lk_non_finite_points_are_lost(O, synth):
+    """cvFloor on the reference's x86 build is cvttss2si: NaN, infinities and values outside the int range all become
+    INT_MIN, fail LKTrackerInvoker's bounds test on every level and leave status 0, err 0 and the (scaled and re-doubled,
+    hence unchanged) input coordinate"""
+    A, B, _ = synth.frame_pair(160, 96)
+    pts = np.array([[np.nan, 20], [30, np.nan], [np.inf, 20], [30, -np.inf], [3e9, 20], [30, -1e20], [60, 40]], np.float32)
+    for order in (O.ORDER_RASTER, O.ORDER_WAVE64):
+        xy, st, err, _ = O.lk_track(A, B, pts, None, O.lk_params(win=(9, 9), max_level=2, max_iters=10, eps=0.01, flags=0), order=order)
+        assert st.tolist() == [0, 0, 0, 0, 0, 0, 1] and not err[:6].any()
+        assert np.array_equal(xy[:6], pts[:6], equal_nan=True)
