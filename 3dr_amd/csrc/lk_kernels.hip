@@ -443,7 +443,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
 
             const int stop_eps = ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) ? 1 : 0;
             if (__builtin_amdgcn_readfirstlane(stop_eps)) break;
-            const int stop_osc = (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) ? 1 : 0;
+            // std::abs(float) < 0.01 (a double) holds exactly for the floats <= 0.01f, the largest float below 0.01
+            const int stop_osc = (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) ? 1 : 0;
             if (__builtin_amdgcn_readfirstlane(stop_osc)) {
                 nx -= dx * 0.5f; ny -= dy * 0.5f;
                 break;
