@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
     // lane-item geometry (fixed for the whole kernel)
     int itx[NPASS], ity[NPASS], loff[NPASS];   // loff: lane's dword offset inside the staged region
     bool ivalid[NPASS];
+    uint32_t m01[NPASS], m23[NPASS];           // int16-pair masks of the taps inside the window's last column
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int q = p * 64 + lane;
@@ -277,6 +278,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         ity[p] = (int)(__umul24((unsigned)q, (unsigned)a.rpr_magic) >> 16);     // q / rpr (host-made reciprocal)
         itx[p] = 4 * (q - ity[p] * rpr);
         loff[p] = ity[p] * lpd + (itx[p] >> 2);
+        const int n = win_w - itx[p];          // taps of this item inside the window (>= 1)
+        m01[p] = n >= 2 ? 0xffffffffu : 0x0000ffffu;
+        m23[p] = n >= 4 ? 0xffffffffu : (n == 3 ? 0x0000ffffu : 0u);
     }
 
     int   status = 1;
@@ -364,11 +368,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
                             d1[k] = (okx && v1) ? q1[xx] : 0u;
                         }
                     }
+                    // One-pass kernel: every tap is computed (the loads cover all four) and the taps beyond the window's
+                    // last column get zero gradients through the pair masks, which removes them from every sum; that
+                    // frees the four exec masks (SGPR pairs) the branches keep alive.  The multi-pass kernels are short of
+                    // VGPRs instead and branch.
                     int gx[4], gy[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         gx[k] = 0; gy[k] = 0;
-                        if (itx[p] + k < win_w) {
+                        if (NPASS == 1 || itx[p] + k < win_w) {
                             const uint32_t sel = k == 0 ? sel0 : k == 1 ? sel1 : k == 2 ? sel2 : sel3;
                             Ib[p][k] = BILIN_ROUND - (bilin_u8(r, sel, W, BILIN_ROUND) << (W_BITS - 5));
                             gx[k] = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
@@ -377,7 +385,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const uint32_t x2 = pack_s16(gx[2 * h], gx[2 * h + 1]), y2 = pack_s16(gy[2 * h], gy[2 * h + 1]);
+                        const uint32_t mh = NPASS == 1 ? (h ? m23[p] : m01[p]) : 0xffffffffu;
+                        const uint32_t x2 = pack_s16(gx[2 * h], gx[2 * h + 1]) & mh, y2 = pack_s16(gy[2 * h], gy[2 * h + 1]) & mh;
                         Ix[p][h] = x2; Iy[p][h] = y2;
                         s11 = dot_s16(x2, x2, s11);
                         s12 = dot_s16(x2, y2, s12);
