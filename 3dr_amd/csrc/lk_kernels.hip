@@ -281,6 +281,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         const int n = win_w - itx[p];          // taps of this item inside the window (>= 1)
         m01[p] = n >= 2 ? 0xffffffffu : 0x0000ffffu;
         m23[p] = n >= 4 ? 0xffffffffu : (n == 3 ? 0x0000ffffu : 0u);
+        if (NPASS == 1 && !ivalid[p]) {
+            // one-pass kernel: lanes beyond the last item shadow item 0 (same, safe addresses) with all-zero masks, so
+            // neither the template nor the iterations need a branch around them
+            itx[p] = 0; ity[p] = 0; loff[p] = 0; m01[p] = 0u; m23[p] = 0u;
+        }
     }
 
     int   status = 1;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
 #pragma unroll
                 for (int k = 0; k < 4; ++k) Ib[p][k] = 0;
                 Ix[p][0] = Ix[p][1] = Iy[p][0] = Iy[p][1] = 0u;
-                if (ivalid[p]) {
+                if (NPASS == 1 || ivalid[p]) {
                     const int x = ipx + itx[p], y = ipy + ity[p];
                     Rows r;
                     uint32_t d0[5], d1[5];     // packed (Ix | Iy<<16) of rows y, y+1, columns x..x+4
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
             int s1 = 0, s2 = 0;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                if (ivalid[p]) {
+                if (NPASS == 1 || ivalid[p]) {
                     const Rows r = lds_rows(lds, lpd, base, loff[p]);
                     // taps beyond the window's last column carry Ix = Iy = 0: whatever mismatch they see adds nothing
                     const uint32_t m01 = pack_s16(bilin_u8(r, sel0, W, Ib[p][0]), bilin_u8(r, sel1, W, Ib[p][1]));
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
             float se = 0.f;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                if (ivalid[p]) {
+                if (p * 64 + lane < a.n_items) {           // recomputed here: nothing else keeps this mask alive in the one-pass kernel
                     const Rows r = lds_rows(lds, lpd, base, loff[p]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
