@@ -247,7 +247,9 @@ __device__ __forceinline__ Rows lds_rows(const uint32_t* __restrict__ lds, int l
     return r;
 }
 
-template <int NPASS>
+// WIN > 0: a square WIN x WIN window known at compile time (the sizes the reference and OpenCV's default use); the window
+// geometry then folds into immediates instead of living in SGPRs, of which this kernel is short.  WIN = 0: any window.
+template <int NPASS, int WIN>
 // 15x15-class windows (one pass): 8 waves per SIMD need <= 96 SGPRs; the compiler parks the excess in VGPR lanes
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ? 8 : 4))) void lk_track_kernel(const LKArgs a)
 {
@@ -262,8 +264,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
     const float ppx = a.prev_xy[2 * pidx], ppy = a.prev_xy[2 * pidx + 1];
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
-    const int win_w = a.win_w, win_h = a.win_h, rpr = a.rpr;
-    const int rwd = a.rwd, rh = a.rh, lpd = a.lpd;
+    const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h, rpr = WIN ? (WIN + 3) / 4 : a.rpr;
+    const int rwd = WIN ? (WIN + 3) / 4 + 3 : a.rwd, rh = WIN ? WIN + 9 : a.rh, lpd = WIN ? (((WIN + 3) / 4 + 3) | 1) : a.lpd;
+    const int cw_shift = WIN ? ((WIN + 3) / 4 + 3 <= 8 ? 3 : 4) : a.cw_shift;
+    const int n_items = WIN ? ((WIN + 3) / 4) * WIN : a.n_items;
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
 
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int q = p * 64 + lane;
-        ivalid[p] = q < a.n_items;
-        ity[p] = (int)(__umul24((unsigned)q, (unsigned)a.rpr_magic) >> 16);     // q / rpr (host-made reciprocal)
+        ivalid[p] = q < n_items;
+        ity[p] = WIN ? q / ((WIN + 3) / 4) : (int)(__umul24((unsigned)q, (unsigned)a.rpr_magic) >> 16);     // q / rpr (host-made reciprocal)
         itx[p] = 4 * (q - ity[p] * rpr);
         loff[p] = ity[p] * lpd + (itx[p] >> 2);
         const int n = win_w - itx[p];          // taps of this item inside the window (>= 1)
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
             // staging centre so the (unused) region stays addressable
             const int cxs = sx < -win_w ? -win_w : (sx >= L.w ? L.w - 1 : sx);
             const int cys = sy < -win_h ? -win_h : (sy >= L.h ? L.h - 1 : sy);
-            R = stage_region(J, L, cxs, cys, lds, rwd, rh, lpd, a.cw_shift, lane);
+            R = stage_region(J, L, cxs, cys, lds, rwd, rh, lpd, cw_shift, lane);
         }
 
         // ---- template patch + structure tensor ------------------------------------------------
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
             }
             it_count = j + 1;
             if (!region_covers(R, inx, iny, rpr, win_h, rwd, rh))
-                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, a.cw_shift, lane);
+                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, cw_shift, lane);
             const Weights W = make_weights(cx - fcx, cy - fcy);
             const int o = inx & 3;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
                 continue;
             }
             if (!region_covers(R, inx, iny, rpr, win_h, rwd, rh))
-                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, a.cw_shift, lane);
+                R = stage_region(J, L, inx, iny, lds, rwd, rh, lpd, cw_shift, lane);
             const Weights W = make_weights(fx - (float)inx, fy - (float)iny);
             const int o = inx & 3;
             const uint32_t sel0 = tap_sel(o, 0), sel1 = tap_sel(o, 1), sel2 = tap_sel(o, 2), sel3 = tap_sel(o, 3);
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
             float se = 0.f;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                if (p * 64 + lane < a.n_items) {           // recomputed here: nothing else keeps this mask alive in the one-pass kernel
+                if (p * 64 + lane < n_items) {           // recomputed here: nothing else keeps this mask alive in the one-pass kernel
                     const Rows r = lds_rows(lds, lpd, base, loff[p]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -518,11 +522,13 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
     const int npass = (a.n_items + 63) / 64;
     dim3 grid(a.n_pts, n_pairs), block(64);
     const size_t shmem = (size_t)a.rh * a.lpd * sizeof(uint32_t);
+    if (a.win_w == 15 && a.win_h == 15) { hipLaunchKernelGGL((lk_track_kernel<1, 15>), grid, block, shmem, s, a); return hipGetLastError(); }
+    if (a.win_w == 21 && a.win_h == 21) { hipLaunchKernelGGL((lk_track_kernel<2, 21>), grid, block, shmem, s, a); return hipGetLastError(); }
     switch (npass) {
-    case 1: hipLaunchKernelGGL((lk_track_kernel<1>), grid, block, shmem, s, a); break;
-    case 2: hipLaunchKernelGGL((lk_track_kernel<2>), grid, block, shmem, s, a); break;
-    case 3: hipLaunchKernelGGL((lk_track_kernel<3>), grid, block, shmem, s, a); break;
-    case 4: hipLaunchKernelGGL((lk_track_kernel<4>), grid, block, shmem, s, a); break;
+    case 1: hipLaunchKernelGGL((lk_track_kernel<1, 0>), grid, block, shmem, s, a); break;
+    case 2: hipLaunchKernelGGL((lk_track_kernel<2, 0>), grid, block, shmem, s, a); break;
+    case 3: hipLaunchKernelGGL((lk_track_kernel<3, 0>), grid, block, shmem, s, a); break;
+    case 4: hipLaunchKernelGGL((lk_track_kernel<4, 0>), grid, block, shmem, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

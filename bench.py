@@ -409,7 +409,7 @@ def main(argv=None):
                                        "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": ach_pass / HBM_PEAK_GBPS, "traffic": None,
                                        "algorithmic_bytes_per_pass": b_pass, "avg_pass_ms": pass_ms},
-            "lk_kernel": {"kernel": "lk_track_kernel<%d>" % ((((WIN + 3) // 4) * WIN + 63) // 64), "avg_launch_ms": lk_ms,
+            "lk_kernel": {"kernel": "lk_track_kernel<%d, %d>" % ((((WIN + 3) // 4) * WIN + 63) // 64, WIN if WIN in (15, 21) else 0), "avg_launch_ms": lk_ms,
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "VALU-issue bound, not HBM-bound (SURVEY 8d): no HBM fraction claimed",

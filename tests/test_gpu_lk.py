@@ -131,7 +131,7 @@ def test_reference_literals_30x30_maxlevel4(dr3, O, synth, ctx):
     assert dr3.lk_effective_max_level(synth.KITTI_W, synth.KITTI_H, 30, 30, 4) == 3
 
 
-@pytest.mark.parametrize("win", [(5, 5), (7, 9), (13, 13), (16, 16), (21, 21), (24, 11), (31, 31), (32, 32)])
+@pytest.mark.parametrize("win", [(5, 5), (7, 9), (13, 13), (15, 15), (16, 16), (15, 21), (21, 21), (24, 11), (24, 24), (31, 31), (32, 32)])
 def test_window_shapes(dr3, O, synth, ctx, win):
     """every lane-item pass count (1..4), even/odd and non-square windows"""
     A, B, T = synth.frame_pair(400, 300)

@@ -95,12 +95,12 @@ def main(src, dst):
         med = {}
         for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"):
             for k, v in per_kernel(p, c).items():
-                if "lk_track_kernel<1>" in k:
+                if "lk_track_kernel<1" in k:
                     big = [x for x in v] if c != "SQ_WAVES" else v
                     med[c] = statistics.median(big)
         if med.get("SQ_WAVES"):
             w = med["SQ_WAVES"]
-            json.dump({"note": "lk_track_kernel<1> at the bench launch shape (256 pairs x 2000 points), rocprofv3 --pmc, "
+            json.dump({"note": "lk_track_kernel<1, 15> at the bench launch shape (256 pairs x 2000 points), rocprofv3 --pmc, "
                                "median over the dispatches of bench.py --steps 2 --warmup 1",
                        "waves": w, "valu_per_wave": med["SQ_INSTS_VALU"] / w, "salu_per_wave": med["SQ_INSTS_SALU"] / w,
                        "vmem_rd_per_wave": med["SQ_INSTS_VMEM_RD"] / w, "lds_per_wave": med["SQ_INSTS_LDS"] / w,
