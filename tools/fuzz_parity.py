@@ -31,6 +31,8 @@ for case in range(n_cases):
     # ---- LK
     w, h = int(rng.integers(40, int(os.environ.get("FUZZ_MAXW", "700")))), int(rng.integers(36, int(os.environ.get("FUZZ_MAXH", "420"))))
     win = (int(rng.integers(3, 33)), int(rng.integers(3, 33)))
+    if rng.random() < 0.25:                        # the compile-time window instantiations
+        win = (15, 15) if rng.random() < 0.5 else (21, 21)
     if ((win[0] + 3) // 4) * win[1] > 256 or w <= win[0] + 2 or h <= win[1] + 2:
         continue
     ml = int(rng.integers(0, 6)); flags = int(rng.choice([0, 4, 8, 12]))
