@@ -49,7 +49,11 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // v_med3_f32 returns the smaller bound when an operand is NaN; the conversion then saturates to INT_MIN.
 __device__ __forceinline__ int floor_to_int(float floored)
 {
-    return (int)__builtin_amdgcn_fmed3f(floored, -3.0e9f, 3.0e9f);
+    int i = (int)__builtin_amdgcn_fmed3f(floored, -3.0e9f, 3.0e9f);
+    // Every caller broadcasts the result with v_readfirstlane.  Without this (empty) barrier the compiler hoists the
+    // broadcast above the conversion, converts from the SGPR on the VALU and broadcasts again: one more instruction.
+    asm volatile("" : "+v"(i));
+    return i;
 }
 
 __device__ __forceinline__ int reflect101(int p, int n)
@@ -328,8 +332,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
         const uint8_t* __restrict__ J = L.img + (long long)ns * L.step;
         Region R;
         {
-            const int sx = __builtin_amdgcn_readfirstlane((int)floorf(cx - half_x));
-            const int sy = __builtin_amdgcn_readfirstlane((int)floorf(cy - half_y));
+            const int sx = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(cx - half_x)));
+            const int sy = __builtin_amdgcn_readfirstlane(floor_to_int(floorf(cy - half_y)));
             // a start outside the level is rejected by the first iteration's bounds test; clamp the
             // staging centre so the (unused) region stays addressable
             const int cxs = sx < -win_w ? -win_w : (sx >= L.w ? L.w - 1 : sx);
