@@ -16,8 +16,12 @@
 //      bilinear J taps (the template value rides in the dot's accumulator, so the dot yields the
 //      mismatch directly), mismatches packed in int16 pairs and multiplied onto the packed
 //      gradients with v_dot2_i32_i16 again: 6.5 VALU per tap;
-//   4. reduces the two sums across the wave with one v_permlane32_swap + DPP adds (no LDS),
-//      solves the 2x2 system redundantly in every lane and tests the wave-uniform exit conditions.
+//   4. reduces the two sums across the wave with v_permlane32_swap + v_permlane16_swap + DPP adds (no
+//      LDS), solves the 2x2 system redundantly in every lane and tests the wave-uniform exit conditions.
+// Scalar registers are the scarce resource (96 at the 8 waves per SIMD the one-pass kernel is pinned to):
+// the 15x15 and 21x21 windows have compile-time instantiations (WIN), and the one-pass kernel drops
+// out-of-window taps and idle lanes through zero masks on the packed gradients instead of branches whose
+// exec masks would occupy SGPR pairs for the kernel's lifetime.
 // If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged
 // around it, so results never depend on the margin.
 // Border handling: OpenCV pads every level by winSize (REFLECT_101 for images, zeros for
