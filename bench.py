@@ -47,6 +47,8 @@ INTRINSICS = (718.856, 718.856, 607.1928, 185.2157, float(KITTI_W), float(KITTI_
 class Dist:
     def __init__(self, n_gpus, backend=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != int(n_gpus):
+            raise ValueError("--gpus %d but WORLD_SIZE is %d: one rank per GPU" % (n_gpus, self.world))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
@@ -106,6 +108,42 @@ class Dist:
         if self.pg:
             self.dist.destroy_process_group()
             self.pg = False
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh child processes, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), relay
+    rank 0's stdout (the JSON line), return the first non-zero exit code.  This process has not imported torch and has
+    made no HIP call, and it never replaces itself: the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this host driver
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+                for q in live:                                     # exactly the PIDs started above
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def timed_region(dist, step_fn, sync_fn, steps, warmup):
@@ -235,6 +273,15 @@ def main(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
+    if env_world is not None and int(env_world) != args.gpus:
+        print("bench.py: --gpus %d disagrees with WORLD_SIZE=%s (launch N ranks with --gpus N, or drop the launcher)"
+              % (args.gpus, env_world), file=sys.stderr)
+        return 2
     global N_PTS, WIN, MAX_LEVEL, INTRINSICS
     grid_cell, period, workload_name = 15, 9, ("configs[1]: KITTI-00-shaped stream 1241x376 u8, 2000 corners/frame, 4-level pyr (maxLevel 3), "
                                                "15x15 window, 30 LK iters (COUNT+EPS 0.01)")
@@ -254,21 +301,33 @@ def main(argv=None):
     # DR3_BENCH_BACKEND=gloo rehearses the N>1 protocol on a box with fewer GPUs than ranks (the ranks then
     # share devices; RCCL refuses two ranks on one GPU).  The driver's runs use the default, nccl == RCCL.
     # DR3_BENCH_FORCE_PG=1 runs the process-group code (RCCL id hand-over, broadcast leg) even at world size 1.
-    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DR3_BENCH_FORCE_PG") == "1"
+    world = int(env_world or "1")
+    multi = world > 1 or os.environ.get("DR3_BENCH_FORCE_PG") == "1"
     backend = os.environ.get("DR3_BENCH_BACKEND", "nccl") if multi else None
-    dist = Dist(args.gpus, backend=backend)
-    dr3 = importlib.import_module("3dr_amd")
+    # DR3_BENCH_STANDIN=<module under tests/>: TEST-ONLY rehearsal of the launch path on a box without GPUs.  The module
+    # replaces the product package with timing stubs (no compute, no oracle); the JSON line then says "data": "standin"
+    # and is not a measurement.  Without it the product library and a HIP device are required (no CPU fallback).
+    standin = os.environ.get("DR3_BENCH_STANDIN")
+    dr3 = importlib.import_module(standin if standin else "3dr_amd")
     synth = importlib.import_module("3dr_amd.synth")
+    n_dev = dr3.lib().dr3hip_device_count()
+    if world > 1 and backend != "gloo" and n_dev < world:
+        # every rank sees the same count and leaves here, before any rendezvous: nobody is left waiting
+        print("bench.py: %d ranks need %d GPUs, dr3hip_device_count() = %d (ranks never share a device over RCCL)"
+              % (world, world, n_dev), file=sys.stderr)
+        return 4
+    dist = Dist(args.gpus, backend=backend)
 
     fx, fy, cx, cy, Wf, Hf = dist.bcast_intrinsics(INTRINSICS)
     W, H = int(Wf), int(Hf)
     B = args.batch
-    n_dev = dr3.lib().dr3hip_device_count()
     ctx = dr3.Context(dist.local_rank % max(n_dev, 1))
+    have_gpu = not standin
 
     def sync():
         ctx.sync()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
     # ---- resident inputs ------------------------------------------------------------------------
     frames, base = stream_frames(synth, B + 1, W, H, period=period)
@@ -310,7 +369,7 @@ def main(argv=None):
     # ---- result check against the oracle (rank 0, pair 0) -------------------------------------------
     verified = None
     tracked_frac = float(d_st.download((B, N_PTS), np.uint8).mean())
-    if dist.rank == 0:
+    if dist.rank == 0 and have_gpu:
         from oracle import oracle as O
         po = O.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
         o_xy, o_st, o_err, _ = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_WAVE64)
@@ -320,7 +379,7 @@ def main(argv=None):
 
     # ---- what this box's HBM delivers on a plain device-to-device copy (report beside the nominal 8 TB/s)
     copy_gbps = None
-    if dist.rank == 0:
+    if dist.rank == 0 and have_gpu:
         try:
             a_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % ctx.device); b_t = torch.empty_like(a_t)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -396,7 +455,7 @@ def main(argv=None):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if have_gpu else "standin (launch-path rehearsal without a GPU: NOT a measurement)",
             "config": {"workload": workload_name,
                        "frame_pairs_per_step_per_gpu": B, "points_per_pair": N_PTS,
                        "sequences": dist.world, "parallelism": "one sequence per GPU, no data-path collective",
@@ -429,9 +488,10 @@ def main(argv=None):
         }
         print(json.dumps(out), flush=True)
 
-    if leg_hung:                 # a thread is still inside RCCL: no orderly teardown is possible
-        sys.stdout.flush()
-        os._exit(0)
+    if leg_hung:                 # a thread is still inside RCCL: no orderly teardown is possible, and the run FAILED
+        print("bench.py: the reference-pyramid broadcast leg did not complete (see ref_pyramid_bcast.error)", file=sys.stderr)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
     for d in (d_prev, d_next, d_st, d_err):
         d.free()
     batch.close()
