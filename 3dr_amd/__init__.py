@@ -21,7 +21,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdr3hip.so")
+LIB_PATH = os.environ.get("DR3HIP_LIB") or os.path.join(_HERE, "libdr3hip.so")   # DR3HIP_LIB: kernel experiments (tools/) only
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dr3hip.h")
 

@@ -886,15 +886,21 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
     for (int l = 0; l <= L; ++l) {
         LevelDev& v = b->lv[l];
         v.w = lw; v.h = lh;
-        // levels >= 1 carry OpenCV's winSize border physically (lk_kernels.hip): wide enough for the template window,
-        // the staged search region (window + 4 px margin) and their dword alignment slop
-        v.pad_x = l ? align_up(win_w + 16, 4) : 0;
-        v.pad_y = l ? win_h + 6 : 0;
+        // every level carries OpenCV's winSize border physically (lk_kernels.hip): wide enough for the template window,
+        // the staged search region (window + 4 px margin) and their dword alignment slop.  Level 0's is a multiple of 64 so
+        // that the interior rows the fused pyramid kernel streams keep their 64-byte alignment.
+        v.pad_x = l ? align_up(win_w + 16, 4) : align_up(win_w + 16, 64);
+        v.pad_y = win_h + 6;
         v.pitch = align_up(lw + 2 * v.pad_x + 8, 64);
         v.dpitch = align_up(4 * (lw + 2 * v.pad_x) + 16, 128);
         const int rows = lh + 2 * v.pad_y;
-        v.step = (long long)align_up(v.pitch * rows, 256);
-        v.dstep = (long long)align_up(v.dpitch * rows, 256);
+        // the kernels address a plane with 31-bit byte offsets
+        if ((long long)v.dpitch * rows > 0x7fffff00ll) {
+            dr3hip_batch_destroy(b);
+            return fail(ctx, DR3HIP_ERANGE, "batch_create: level %d plane of %d x %d exceeds the 2 GiB a plane may span", l, lw, lh);
+        }
+        v.step = align_up((long long)v.pitch * rows, 256ll);
+        v.dstep = align_up((long long)v.dpitch * rows, 256ll);
         const size_t ib = (size_t)v.step * capacity + 256, db = (size_t)v.dstep * capacity + 256;
         void *pi = nullptr, *pd = nullptr;
         if (hipMalloc(&pi, ib) != hipSuccess || hipMalloc(&pd, db) != hipSuccess) {
@@ -998,9 +1004,9 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             prof_end(ctx, p0);
         }
     }
-    // the physical REFLECT_101 border of levels 1 .. L (read by the tracker only, never by the pyramid kernels): one launch
-    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768)
-        HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
+    // the physical REFLECT_101 border of every level (read by the tracker only, never by the pyramid kernels): one launch
+    for (int s0 = 0; s0 < count; s0 += 32768)
+        HIPCHK(ctx, launch_pad_reflect(&b->lv[0], L + 1, first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

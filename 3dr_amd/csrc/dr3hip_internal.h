@@ -20,8 +20,9 @@ struct LevelDev {
     int dpitch;            // bytes per derivative row (>= 4*w, multiple of 128)
     long long step;        // bytes between slots (image)
     long long dstep;       // bytes between slots (derivative)
-    int pad_x, pad_y;      // physical border around the plane (levels >= 1): REFLECT_101 pixels / zero derivatives, so the
-                           // tracker never leaves the fast path there; img / der point at the interior origin.  0 = none
+    int pad_x, pad_y;      // physical border around the plane: REFLECT_101 pixels / zero derivatives (OpenCV pads every level
+                           // by winSize the same way), so the tracker addresses every window plainly; img / der point at
+                           // the interior origin.  pad_x is a multiple of 4.  0 = none (planes outside a frame batch)
 };
 
 struct PyrArgs {
@@ -157,6 +158,7 @@ hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 
 // geometry helpers shared by host and launchers
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 static inline int type_channels(int type) {
     switch (type) { case DR3HIP_8UC1: return 1; case DR3HIP_8UC3: return 3; case DR3HIP_8UC4: return 4;
                     case DR3HIP_32FC4: return 4; case DR3HIP_32FC1: return 1; default: return 0; }

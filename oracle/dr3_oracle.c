@@ -160,39 +160,50 @@ static inline int der_at(const lvl_deriv* D, int x, int y, int c)
 /* Window-sum accumulator that can emulate either summation order. */
 typedef struct {
     int   order;
-    int   win_w, rpr;             /* runs per row for WAVE64 */
+    int   win_w, rpr;             /* lane-items per window row in the kernel's order */
+    int   tap_shift, lanes;       /* kernel's order: log2(taps per lane-item) and lanes per point (64, or 32 = half a wave) */
     long long lane[3][64];        /* up to three simultaneous sums: the lane-local part is an exact integer sum */
     float acc[3];
 } wsum;
 
-static void wsum_init(wsum* s, int order, int win_w)
+/* The HIP tracker has two shapes (3dr_amd/csrc/lk_kernels.hip).  Windows of at most 32 lane-items of 8 taps
+ * (ceil(win_w / 8) * win_h <= 32: every window up to 16x16, e.g. the bench's 15x15) are tracked by HALF a wave, two points
+ * per wave64; larger windows by a whole wave with lane-items of 4 taps.  DR3O_ORDER_WAVE64 follows whichever applies. */
+static int kernel_order_is_half_wave(int win_w, int win_h) { return ((win_w + 7) / 8) * win_h <= 32; }
+
+static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {
-    s->order = order; s->win_w = win_w; s->rpr = (win_w + 3) / 4;
+    s->order = order; s->win_w = win_w;
+    if (kernel_order_is_half_wave(win_w, win_h)) { s->tap_shift = 3; s->lanes = 32; }
+    else { s->tap_shift = 2; s->lanes = 64; }
+    s->rpr = (win_w + (1 << s->tap_shift) - 1) >> s->tap_shift;
     memset(s->lane, 0, sizeof(s->lane));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
 }
 /* Every term of the three LK window sums is an integer (a product of two fixed-point values, or |diff|).
  * RASTER (OpenCV's scalar path): converted to f32 and added in raster order, each add rounding.
- * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx/4); pass = q/64, lane = q%64; the taps of one lane are summed
- * as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so int32 cannot overflow in the
- * kernel), converted to f32 once, and the 64 lane values go through the f32 tree of wsum_get. */
+ * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx >> tap_shift); lane = q % lanes (whole-wave shape: pass = q / 64);
+ * the taps of one lane are summed as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so
+ * int32 cannot overflow in the kernel), converted to f32 once, and the lane values go through the f32 tree of wsum_get. */
 static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)
 {
     if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += (float)v; return; }
     {
-        const int q = ty * s->rpr + (tx >> 2);
-        s->lane[which][q & 63] += v;
+        const int q = ty * s->rpr + (tx >> s->tap_shift);
+        s->lane[which][q & (s->lanes - 1)] += v;
     }
 }
 static float wsum_get(wsum* s, int which)
 {
     if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
     {
-        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3): fold the upper half-wave
-         * onto the lower, the upper 16 of those onto the lower 16, then an xor butterfly 1,2,4,8 */
+        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3 and half_sum2 / half_sum3): whole-wave
+         * shape: fold the upper half-wave onto the lower first; both shapes: fold the upper 16 of the 32 values onto the
+         * lower 16, then an xor butterfly 1,2,4,8 */
         float a[32], c[16], b[16];
         int off, l;
-        for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
+        if (s->lanes == 64) for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
+        else                for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l];
         for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
         for (off = 1; off < 16; off <<= 1) {
             for (l = 0; l < 16; ++l) b[l] = c[l] + c[l ^ off];
@@ -256,7 +267,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
         iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-        wsum_init(&S, order, win_w);
+        wsum_init(&S, order, win_w, win_h);
         for (y = 0; y < win_h; ++y) {
             for (x = 0; x < win_w; ++x) {
                 const int X = ipx + x, Y = ipy + y;
@@ -311,7 +322,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-            wsum_init(&S, order, win_w);
+            wsum_init(&S, order, win_w, win_h);
             for (y = 0; y < win_h; ++y) {
                 for (x = 0; x < win_w; ++x) {
                     const int X = inx + x, Y = iny + y;
@@ -355,7 +366,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-            wsum_init(&S, order, win_w);
+            wsum_init(&S, order, win_w, win_h);
             for (y = 0; y < win_h; ++y) {
                 for (x = 0; x < win_w; ++x) {
                     const int X = inx + x, Y = iny + y;

@@ -1,8 +1,6 @@
+# times every library variant under gpurun_in/ (built in the authoring container with different -D flags) on one box
 set -e
 cd $GRAFT_REPO_ROOT
-for v in "" "-DDR3_DBG_NO_DERIV" "-DDR3_DBG_NO_STAGE" "-DDR3_DBG_NO_DERIV -DDR3_DBG_NO_STAGE"; do
-  touch 3dr_amd/csrc/lk_kernels.hip
-  make -C 3dr_amd/csrc EXTRA="$v" > /dev/null 2>&1
-  echo "variant [$v]"
-  python tools/lk_sweep.py 2>&1 | grep -E "levels 4 iters  0|levels 4 iters 30|levels 1 iters  0"
+for f in gpurun_in/libdr3hip_*.so; do
+  DR3HIP_LIB=$PWD/$f timeout -k 10 200 python tools/lk_time.py "$@" 2>&1 | tail -1
 done

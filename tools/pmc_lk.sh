@@ -1,10 +1,13 @@
+# LK tracker pipe utilisation at the bench's launch shape: rocprofv3 --pmc passes (counters only: no other trace domain;
+# the program itself after "--"), then per-kernel medians.  usage: bash tools/pmc_lk.sh [extra bench.py args]
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-frontend --no-host-api $@"
 run() { n=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_lk_$n -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-warp --no-frontend --no-host-api > $R/gpurun_out/pmc_lk_$n.log 2>&1 || echo "pmc $n failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_lk_$n -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_lk_$n.log 2>&1 || echo "pmc $n failed"
 }
-run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS
-run b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU
-run c GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+run a GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
+run b GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU
+run c GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU
 python3 $R/tools/pmc_medians.py $R/gpurun_out pmc_lk_ | tee $R/gpurun_out/pmc_lk_summary.txt
