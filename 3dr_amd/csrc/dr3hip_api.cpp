@@ -1006,7 +1006,7 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
     }
     // the physical REFLECT_101 border of every level (read by the tracker only, never by the pyramid kernels): one launch
     for (int s0 = 0; s0 < count; s0 += 32768)
-        HIPCHK(ctx, launch_pad_reflect(&b->lv[0], L + 1, first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
+        HIPCHK(ctx, launch_pad_reflect(&b->lv[0], L + 1, align_up(b->win_w + 16, 4), first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

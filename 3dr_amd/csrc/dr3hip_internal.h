@@ -35,6 +35,8 @@ struct PyrArgs {
 
 struct PadArgs {           // pad_reflect_kernel: the padded levels of one build, one launch
     LevelDev lv[DR3HIP_MAX_LEVELS];
+    int fill_x[DR3HIP_MAX_LEVELS];   // border columns written each side (<= pad_x, multiple of 4)
+    int task0[DR3HIP_MAX_LEVELS];    // first wave-task of each level in the flat task list of a frame
     int n_lv, first;
 };
 
@@ -143,7 +145,7 @@ struct HalfArgs {
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
-hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int first, int n_slots, hipStream_t s);
+hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
 
 
 // =====================================================================================================================
-// Two points per wave: windows of at most 32 lane-items of 8 taps (ceil(win_w / 8) * win_h <= 32: every window up to
+// Two points per wave: windows of at most 32 lane-items of 8 taps (win_w <= 16, ceil(win_w / 8) * win_h <= 32: every window up to
 // 16x16, the bench's 15x15 among them).  Half a wave (32 lanes = DPP rows 0-1 or rows 2-3) owns one point; lane-item
 // q = ty * ceil(win_w / 8) + r covers the 8 taps (ty, 8r .. 8r+7).  Everything that is wave-uniform in the kernel above
 // -- window origins, bilinear weights, the 2x2 solve, the exit tests, the reductions' tails -- is computed once per
@@ -586,7 +586,7 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef LK2_WAVES
 #define LK2_WAVES 4
 #endif
-// WIN > 0: square compile-time window (<= 16); WIN = 0: any window with ceil(win_w / 8) * win_h <= 32
+// WIN > 0: square compile-time window (<= 16); WIN = 0: any window with win_w <= 16 and ceil(win_w / 8) * win_h <= 32
 template <int WIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES))) void lk_track2_kernel(const LKArgs a)
 {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
 }  // namespace
 
 // windows the two-points-per-wave kernel takes (the oracle's kernel_order_is_half_wave is the same rule)
-static inline bool lk_half_wave_window(int win_w, int win_h) { return ((win_w + 7) / 8) * win_h <= 32; }
+static inline bool lk_half_wave_window(int win_w, int win_h) { return win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32; }
 
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
 {

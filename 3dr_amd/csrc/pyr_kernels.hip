@@ -174,57 +174,76 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
     }
 }
 
-// REFLECT_101 border of a padded level (levels >= 1 of a batch): OpenCV pads every pyramid level by winSize
-// (SURVEY A-1); doing the same physically for the small levels -- where a third of the windows cross the image edge --
-// keeps the tracker on its fast path there.  One lane per border dword; reads touch the interior only, writes the border
-// (the mixed dword at the right edge rewrites its interior bytes with themselves).  The derivative border is zero from
-// allocation on.
-__global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
+// REFLECT_101 border of the padded levels of a batch: OpenCV pads every pyramid level by winSize (SURVEY A-1); doing the
+// same physically keeps the tracker on plain addressing everywhere.  The work of one frame is a flat list of wave-tasks
+// over all levels (no idle workgroups): a band task is one of the pad_y rows above / below the image (the reflected
+// source row copied with aligned dword loads, byte gathers only at its two ends); a side task is the left + right
+// border dwords of eight interior rows (32 lanes per row).  Only fill_x columns each side are written (what the tracker can
+// read; level 0 reserves more for alignment).  Reads touch the interior only, writes the border (the mixed dword at the right
+// edge rewrites its interior bytes with themselves).  The derivative border is zero from allocation on.
+// Measured (256 KITTI frames, 4 levels): the bands are free next to the launch itself; the side dwords -- 17 narrow
+// accesses per row, 180 000 rows -- cost 30 to 45 us: the next thing to fix (aligned dword pairs + v_perm_b32 reversal
+// instead of byte gathers; 16-byte chunks per lane).
+__device__ __forceinline__ uint32_t border_dword(const uint8_t* __restrict__ srow, int xq, int w)
 {
-    const LevelDev& lv = a.lv[blockIdx.z];                                // grid z = level (1 .. L), y = slot
-    const int first = a.first;
-    // flattened index over the border dwords only: first the 2 pad_y full-width rows above and below, then for every
-    // interior row the pad_x / 4 dwords on the left and the dwords from the last interior one to the right edge
-    const int wq = (lv.w + 2 * lv.pad_x + 3) / 4;                        // dwords per padded row
-    const int lq = lv.pad_x / 4;                                          // left border dwords of an interior row
-    const int r0 = lv.w / 4;                                              // first dword (interior numbering) that is not purely interior
-    const int rq = (lv.w + lv.pad_x + 3) / 4 - r0;                        // right border dwords (incl. the mixed one)
-    const int n_band = 2 * lv.pad_y * wq, n_side = lv.h * (lq + rq);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_band + n_side) return;
-    int xq, y;
-    if (i < n_band) {
-        const int r = i / wq;
-        y = r < lv.pad_y ? r - lv.pad_y : lv.h + (r - lv.pad_y);
-        xq = (i - r * wq) * 4 - lv.pad_x;
-    } else {
-        const int j = i - n_band;
-        y = j / (lq + rq);
-        const int c = j - y * (lq + rq);
-        xq = c < lq ? c * 4 - lv.pad_x : (r0 + (c - lq)) * 4;
-    }
-    uint8_t* img = lv.img + (long long)(first + blockIdx.y) * lv.step;
-    const uint8_t* srow = img + (long long)reflect101(y, lv.h) * lv.pitch;
+    if (xq >= 0 && xq + 3 < w) return *reinterpret_cast<const uint32_t*>(srow + xq);
     uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, lv.w)] << (8 * k);
-    *reinterpret_cast<uint32_t*>(img + (long long)y * lv.pitch + xq) = v;
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, w)] << (8 * k);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int task_all = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    int l = 0;
+    while (l + 1 < a.n_lv && task_all >= a.task0[l + 1]) ++l;           // wave-uniform
+    const int task = task_all - a.task0[l];
+    const LevelDev& lv = a.lv[l];
+    const int fill = a.fill_x[l];
+    const int w = lv.w, h = lv.h, n_band = 2 * lv.pad_y;
+    uint8_t* img = lv.img + (long long)(a.first + blockIdx.y) * lv.step;
+    if (task < n_band) {
+        const int y = task < lv.pad_y ? task - lv.pad_y : h + (task - lv.pad_y);
+        const uint8_t* srow = img + (long long)reflect101(y, h) * lv.pitch;
+        uint8_t* drow = img + (long long)y * lv.pitch;
+        const int wq = (w + 2 * fill + 3) >> 2;                           // dwords of a band row (from x = -fill)
+        for (int q = lane; q < wq; q += 64)
+            *reinterpret_cast<uint32_t*>(drow + (q * 4 - fill)) = border_dword(srow, q * 4 - fill, w);
+    } else {
+        const int lq = fill >> 2;                                         // left border dwords of an interior row
+        const int r0 = w >> 2;                                            // first dword (interior numbering) that is not purely interior
+        const int rq = ((w + fill + 3) >> 2) - r0;                        // right border dwords (incl. the mixed one)
+        const int c = lane & 31;
+        if (c >= lq + rq) return;
+        const int xq = c < lq ? c * 4 - fill : (r0 + (c - lq)) * 4;
+        const int y0 = (task - n_band) * 8 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = y0 + 2 * i;
+            if (y < h) {
+                uint8_t* row = img + (long long)y * lv.pitch;
+                *reinterpret_cast<uint32_t*>(row + xq) = border_dword(row, xq, w);
+            }
+        }
+    }
 }
 
 }  // namespace
 
-hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int first, int n_slots, hipStream_t s)
+hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s)
 {
     if (n_slots <= 0 || n_lv <= 0 || lv[0].pad_x <= 0) return hipSuccess;
     PadArgs a; a.first = first; a.n_lv = n_lv;
-    int n_max = 0;
+    int tasks = 0;
     for (int i = 0; i < n_lv; ++i) {
         a.lv[i] = lv[i];
-        const int wq = (lv[i].w + 2 * lv[i].pad_x + 3) / 4, lq = lv[i].pad_x / 4, rq = (lv[i].w + lv[i].pad_x + 3) / 4 - lv[i].w / 4;
-        const int n = 2 * lv[i].pad_y * wq + lv[i].h * (lq + rq);
-        if (n > n_max) n_max = n;
+        a.fill_x[i] = fill_x < lv[i].pad_x ? fill_x : lv[i].pad_x;
+        a.task0[i] = tasks;
+        tasks += (2 * lv[i].pad_y + (lv[i].h + 7) / 8 + 3) & ~3;          // whole workgroups per level: a wave never straddles two
     }
-    dim3 block(256), grid((n_max + 255) / 256, n_slots, n_lv);           // one launch for every padded level
+    dim3 block(256), grid(tasks / 4, n_slots);                           // one launch for every padded level
     hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -167,9 +167,9 @@ typedef struct {
 } wsum;
 
 /* The HIP tracker has two shapes (3dr_amd/csrc/lk_kernels.hip).  Windows of at most 32 lane-items of 8 taps
- * (ceil(win_w / 8) * win_h <= 32: every window up to 16x16, e.g. the bench's 15x15) are tracked by HALF a wave, two points
+ * (win_w <= 16 and ceil(win_w / 8) * win_h <= 32: every window up to 16x16, e.g. the bench's 15x15) are tracked by HALF a wave, two points
  * per wave64; larger windows by a whole wave with lane-items of 4 taps.  DR3O_ORDER_WAVE64 follows whichever applies. */
-static int kernel_order_is_half_wave(int win_w, int win_h) { return ((win_w + 7) / 8) * win_h <= 32; }
+static int kernel_order_is_half_wave(int win_w, int win_h) { return win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32; }
 
 static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {

@@ -44,7 +44,7 @@ extern "C" {
 
 /* float summation order of the window sums (A11,A12,A22,b1,b2,err) */
 #define DR3O_ORDER_RASTER   0  /* OpenCV's scalar path: y outer, x inner, one f32 accumulator */
-#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order.  Windows of <= 32 lane-items of 8 taps (up to 16x16): 32 lanes (half a wave64 per point);
+#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order.  Windows of <= 32 lane-items of 8 taps (win_w <= 16; up to 16x16): 32 lanes (half a wave64 per point);
                                  * larger windows: 64 lanes x lane-items of 4 taps, upper half-wave folded onto the lower first.  Then both:
                                  * upper 16 onto lower 16, xor butterfly 1,2,4,8 */
 

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""VALU issue cost of the tracker's instruction mix.
+
+MI355X issues a wave64 VALU instruction in 2, 4 or 8 shader clocks depending on the opcode (measured: tools/ubench/valu_rate.hip ->
+profiles/r02_lk/ubench_valu_rate*.json): plain VOP1/VOP2 integer / f32 add, sub, mul, logic, right shifts and moves whose operands
+are VGPRs or inline constants take 2; everything VOP3, every dot / perm / convert / compare / DPP / 64-bit / packed instruction and
+any instruction with an SGPR or literal operand takes 4; transcendentals take 8.  A kernel's VALU-issue roofline therefore depends
+on its own mix.  This tool compiles lk_kernels.hip for gfx950, walks the ISA of one kernel, weights every basic block by its loop
+nest (level loop x iteration loop; deeper loops are the rare re-staging paths) and prints the weighted instruction count per cost
+class and the average issue cost.  bench.py combines the average with the PMC instruction count of the same kernel
+(profiles/*/pmc_lk.json) into lk_kernel.valu_issue.
+
+usage: tools/lk_valu_mix.py [kernel-substring] [levels] [iteration-levels per wave] > profiles/<round>/valu_mix.json
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "3dr_amd", "csrc", "lk_kernels.hip")
+
+FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_ashrrev_i32",
+        "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32"}
+TRANS = {"v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
+NOT_VALU_ISSUE = {"v_readlane_b32", "v_readfirstlane_b32", "v_writelane_b32"}      # counted by SQ_INSTS_VALU, cost 4 like the rest
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in ("lk_kernels.hip", "dr3hip_internal.h"):
+        h.update(open(os.path.join(ROOT, "3dr_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def compile_isa():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "lk.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                               "-fno-fast-math", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                               "-o", out, SRC], stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def cost_of(line):
+    m = re.match(r"\s*(v_[a-z0-9_]+)\s*(.*)", line)
+    if not m:
+        return None
+    op, rest = m.group(1), m.group(2)
+    base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+    if base in TRANS:
+        return 8, "trans"
+    enc64 = op.endswith("_e64") or op.endswith("_dpp") or op.endswith("_sdwa")
+    if base in FAST and not enc64:
+        ops = [o.strip() for o in rest.split(",")]
+        srcs = ops[1:]
+        scalar = any(re.match(r"^(s\d+|s\[|vcc|exec|m0|0x[0-9a-f]+$|-?\d{3,}$)", o) for o in srcs)      # SGPR or literal operand
+        big_int = any(re.match(r"^-?\d+$", o) and not (-16 <= int(o) <= 64) for o in srcs)
+        if not scalar and not big_int:
+            return 2, "fast"
+    return 4, "std"
+
+
+def main():
+    want = sys.argv[1] if len(sys.argv) > 1 else "lk_track2_kernelILi15E"
+    levels = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    iter_levels = float(sys.argv[3]) if len(sys.argv) > 3 else 11.3
+    isa = compile_isa()
+    m = re.search(r"^(_Z\S*%s\S*):[^\n]*\n(.*?)s_endpgm" % re.escape(want), isa, re.S | re.M)
+    if not m:
+        sys.exit("kernel %s not found" % want)
+    body = m.group(2).split("\n")
+    # loop depth of every block from the compiler's annotations
+    depth, header = 0, {}
+    w_of_depth = {0: 1.0, 1: levels, 2: iter_levels}
+    tot = {"fast": 0.0, "std": 0.0, "trans": 0.0}
+    static = {"fast": 0, "std": 0, "trans": 0}
+    cur_depth = 0
+    for i, line in enumerate(body):
+        lm = re.match(r"^\.LBB\d+_\d+:", line)
+        if lm:
+            # the annotation is on this line or the following comment lines
+            ann = " ".join(body[i:i + 8])
+            ann = ann.split("\n")[0]
+            d = 0
+            look = " ".join(l for l in body[i:i + 8] if l.startswith(".LBB") or l.strip().startswith(";"))
+            md = re.search(r"Depth=(\d+)", look)
+            if md:
+                d = int(md.group(1))
+            cur_depth = d
+            continue
+        c = cost_of(line)
+        if c is None:
+            continue
+        clk, cls = c
+        static[cls] += 1
+        tot[cls] += w_of_depth.get(cur_depth, 0.0)
+    n = sum(tot.values())
+    cycles = 2 * tot["fast"] + 4 * tot["std"] + 8 * tot["trans"]
+    out = {"kernel": m.group(1), "source_hash": source_hash(),
+           "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0},
+           "static_valu": static, "weighted_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
+           "weighted_valu_per_wave_total": round(n, 1), "issue_clocks_per_wave": round(cycles, 1),
+           "avg_issue_clocks_per_valu": round(cycles / n, 4),
+           "cost_table": "2 clk: VOP1/VOP2 add/sub/mul f32, add/sub/and/or/xor u32, right shifts, v_mov with VGPR / inline operands; 8 clk: transcendentals; "
+                         "4 clk: everything else (tools/ubench/valu_rate.hip at 8 waves per SIMD, profiles/r02_lk/ubench_valu_rate*.txt)"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@
 #pragma clang diagnostic ignored "-Wunused-result"
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <string>
 
@@ -41,7 +42,33 @@ struct Clk { unsigned long long t0, r0, t1, r1; };
     F(18, "v_mad_u32_u24",       "v_mad_u32_u24 %0, %0, %1, %1") \
     F(19, "v_lshl_add_u32",      "v_lshl_add_u32 %0, %0, 1, %1") \
     F(20, "v_alignbyte_b32",     "v_alignbyte_b32 %0, %0, %1, 1") \
-    F(21, "v_cmp_lt_i32(vcc)",   "v_cmp_lt_i32 vcc, %0, %1")
+    F(21, "v_cmp_lt_i32(vcc)",   "v_cmp_lt_i32 vcc, %0, %1") \
+    F(22, "v_fmac_f32 (VOP2)",   "v_fmac_f32 %0, %1, %1") \
+    F(23, "v_dot2c_i32_i16 (VOP2)", "v_dot2c_i32_i16 %0, %1, %1") \
+    F(24, "v_dot4c_i32_i8 (VOP2)",  "v_dot4c_i32_i8 %0, %1, %1") \
+    F(25, "v_cvt_f32_ubyte0",    "v_cvt_f32_ubyte0 %0, %0") \
+    F(26, "v_cvt_f32_ubyte2",    "v_cvt_f32_ubyte2 %0, %0") \
+    F(27, "v_cvt_i32_f32",       "v_cvt_i32_f32 %0, %0") \
+    F(28, "v_sub_f32",           "v_sub_f32 %0, %0, %1") \
+    F(29, "v_lshrrev_b32",       "v_lshrrev_b32 %0, 1, %0") \
+    F(30, "v_or_b32",            "v_or_b32 %0, %0, %1") \
+    F(31, "v_xor_b32",           "v_xor_b32 %0, %0, %1") \
+    F(32, "v_sub_u32",           "v_sub_u32 %0, %0, %1") \
+    F(33, "v_mul_u32_u24 (VOP2)", "v_mul_u32_u24 %0, %0, %1") \
+    F(34, "v_max_f32",           "v_max_f32 %0, %0, %1") \
+    F(35, "v_lshlrev_b32 by vgpr", "v_lshlrev_b32 %0, %1, %0") \
+    F(36, "v_add_u32 sgpr",      "v_add_u32 %0, %2, %0") \
+    F(37, "v_mul_f32 sgpr",      "v_mul_f32 %0, %2, %0") \
+    F(38, "v_pk_fmac_f16 (VOP2)", "v_pk_fmac_f16 %0, %1, %1") \
+    F(39, "v_max_i32",           "v_max_i32 %0, %0, %1") \
+    F(40, "v_add_f32 e64 (abs)", "v_add_f32_e64 %0, |%0|, %1") \
+    F(41, "v_add3_u32",          "v_add3_u32 %0, %0, %1, %1") \
+    F(42, "v_and_or_b32",        "v_and_or_b32 %0, %0, %1, %1") \
+    F(43, "v_cvt_f32_u32",       "v_cvt_f32_u32 %0, %0") \
+    F(44, "v_mul_i32_i24 (VOP2)", "v_mul_i32_i24 %0, %0, %1") \
+    F(45, "v_mac_f32 legacy? v_fmac dpp", "v_fmac_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+    F(46, "v_bfe_u32",           "v_bfe_u32 %0, %0, 8, 8") \
+    F(47, "v_cndmask_b32 (s pair)", "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
 
 template <int OP> __device__ __forceinline__ void chain(uint32_t& a, uint32_t w, uint32_t sc)
 {
@@ -70,7 +97,7 @@ template <int OP> __global__ __launch_bounds__(256) void k32(uint32_t* out, Clk*
 {
     uint32_t a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i;
-    const uint32_t w = (OP >= 7 && OP <= 12) || OP == 16 || OP == 17 ? 0x3f800001u : (seed | 0x00010001u);
+    const uint32_t w = (OP >= 7 && OP <= 12) || OP == 16 || OP == 17 || OP == 22 || OP == 28 || OP == 34 || OP == 37 || OP == 40 || OP == 45 ? 0x3f800001u : (seed | 0x00010001u);
     const uint32_t sc = 0x05040100u;
     Clk c;
     stamp(c.t0, c.r0);
@@ -146,11 +173,13 @@ template <int MIX> __global__ __launch_bounds__(256) void kmix(uint32_t* out, Cl
 
 struct Row { std::string name; int wps; double ms, ginstr, ghz, clk_per; };
 static std::vector<Row> rows;
+static int g_only_wps = 0;                              // argv[3]: run only this many waves per SIMD (for counter calibration runs)
 
 template <typename K> static void run(const char* name, K kern, uint32_t* d, Clk* dclk, int valu_per_trip, int iters)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int wps : {1, 2, 4, 8}) {                      // waves per SIMD: blocks of 256 threads = one wave on each SIMD of a CU
+        if (g_only_wps && wps != g_only_wps) continue;
         const int blocks = 256 * wps, threads = 256;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, dclk, 64, 7u);
         hipEventRecord(e0);
@@ -173,7 +202,9 @@ int main(int argc, char** argv)
     uint32_t* d; hipMalloc(&d, 256 * 8 * 256 * 4);
     Clk* dclk; hipMalloc(&dclk, sizeof(Clk));
     const int iters = 4000;
-#define F(ID, NAME, TXT) run(NAME, k32<ID>, d, dclk, 64, iters);
+    const int first_op = argc > 2 ? atoi(argv[2]) : 0;
+    g_only_wps = argc > 3 ? atoi(argv[3]) : 0;       // argv[2]: skip the single-opcode streams below this id
+#define F(ID, NAME, TXT) if (ID >= first_op) run(NAME, k32<ID>, d, dclk, 64, iters);
     OP_LIST(F)
 #undef F
     run("v_mul_f64", k64<100>, d, dclk, 64, iters);
