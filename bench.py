@@ -367,15 +367,18 @@ def main(argv=None):
     ctx.profile_enable(False)
 
     # ---- result check against the oracle (rank 0, pair 0) -------------------------------------------
-    verified = None
+    verified, raster = None, None
     tracked_frac = float(d_st.download((B, N_PTS), np.uint8).mean())
     if dist.rank == 0 and have_gpu:
         from oracle import oracle as O
         po = O.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
-        o_xy, o_st, o_err, _ = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_WAVE64)
+        o_xy, o_st, o_err, o_L, o_it = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_WAVE64, want_iters=True)
         g_xy = d_next.download((B, N_PTS, 2), np.float32)[0]
         g_st = d_st.download((B, N_PTS), np.uint8)[0]
         verified = bool(np.array_equal(g_xy, o_xy) and np.array_equal(g_st, o_st))
+        # the same pair in OpenCV's scalar summation order: north_star's 1e-3 px bar (oracle.order_agreement says how it is read)
+        r_res = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_RASTER, want_iters=True)
+        raster = O.order_agreement((g_xy, g_st, None, o_L, o_it), r_res, po, 1e-3)
 
     # ---- what this box's HBM delivers on a plain device-to-device copy (report beside the nominal 8 TB/s)
     copy_gbps = None
@@ -464,6 +467,9 @@ def main(argv=None):
             "warped_mpix_per_sec_1241x376": (warp or {}).get("kitti_frames_8uc3", {}).get("mpix_per_s"),
             "tracked_fraction": tracked_frac,
             "verified_vs_oracle": verified,
+            "raster_within_1e-3_frac": None if raster is None else raster["within_tol_frac"],
+            "raster_max_dev_px": None if raster is None else raster["max_dev_px"],
+            "raster_order_agreement": raster,
             "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)",
                          "bound": "hbm", "achieved": ach_l0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": traffic_l0,
@@ -598,9 +604,14 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
         ctx.profile_enable(False)
         mpix = aggregate_rate(dist, NT_ * TW_ * TH_ * steps / 1e6, el)
         k_ms = ms / max(n, 1)
+        ok = None
+        if dist.rank == 0:                                # tile 0 of the timed launch against the oracle, outside the timed region
+            from oracle import oracle as O
+            got = dsts[0].download(host.shape, host.dtype)
+            ok = bool(np.array_equal(got.view(np.uint8), O.warp_perspective(host, jobs[0]["M"], (TW_, TH_)).view(np.uint8)))
         alg = NT_ * TW_ * TH_ * 2 * esz                  # esz read + esz written per dst pixel
         traffic, tsrc = pmc_traffic("warp_perspective_kernel<%d," % typ, 256, "pmc_traffic_warp.json")
-        res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms,
+        res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms, "verified_vs_oracle": ok,
                      "roofline": {"kernel": "warp_perspective_kernel<%s>" % name.upper(), "bound": "hbm",
                                   "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
@@ -636,10 +647,15 @@ def kitti_warp_leg(dist, ctx, dr3, synth, sync, tile, steps):
     el = timed_region(dist, lambda: dr3.warp_batch(ctx, jobs, dr3.T_8UC3), sync, steps, 0)
     ms, n = ctx.profile_read(dr3.PROF_WARP)
     ctx.profile_enable(False)
+    ok = None
+    if dist.rank == 0:
+        from oracle import oracle as O
+        got = d_dst.download((H_, pitch), np.uint8, offset=3 * H_ * pitch)[:, :3 * W_].reshape(H_, W_, 3)     # frame 3 of the launch
+        ok = bool(np.array_equal(got, O.warp_perspective(frame, jobs[3]["M"], (W_, H_))))
     d_src.free(); d_dst.free()
     k_ms = ms / max(n, 1)
     alg = NJ * W_ * H_ * 6
-    return {"frames_per_launch": NJ, "kernel_ms": k_ms, "mpix_per_s": aggregate_rate(dist, NJ * W_ * H_ * steps / 1e6, el),
+    return {"frames_per_launch": NJ, "kernel_ms": k_ms, "verified_vs_oracle": ok, "mpix_per_s": aggregate_rate(dist, NJ * W_ * H_ * steps / 1e6, el),
             "kernel_only_mpix_per_s": NJ * W_ * H_ / 1e6 / (k_ms * 1e-3),
             "roofline": {"kernel": "warp_perspective_kernel<8UC3>", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
@@ -668,11 +684,16 @@ def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
     el = timed_region(dist, step, sync, steps, 0)
     ms, n = ctx.profile_read(dr3.PROF_STITCH)
     ctx.profile_enable(False)
+    ok = None
+    if dist.rank == 0:                                     # the timed pair against the oracle's two warps + addWeighted
+        from oracle import oracle as O
+        got = d_o.download((nh, op), np.uint8)[:, :3 * nw].reshape(nh, nw, 3)
+        ok = bool(np.array_equal(got, O.stitch_compose(tile, np.roll(tile, -int(0.45 * TW_), axis=1), H)))
     for d in (d_l, d_r, d_o):
         d.free()
     k_ms = ms / max(n, 1)
     alg = 2 * TW_ * TH_ * 3 + nw * nh * 3                 # both sources read once + the canvas written once
-    return {"canvas": [nw, nh], "kernel_ms": k_ms, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
+    return {"canvas": [nw, nh], "kernel_ms": k_ms, "verified_vs_oracle": ok, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
             "roofline": {"kernel": "stitch_compose_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
             "replaces": "reference passes: warp right (3 r + 3 w per canvas px), warp left (3 r + 3 w), addWeighted (6 r + 3 w)"}
@@ -709,6 +730,21 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
     ms_add, n_add = ctx.profile_read(dr3.PROF_PANO_ADD)
     ms_norm, n_norm = ctx.profile_read(dr3.PROF_PANO_NORM)
     ctx.profile_enable(False)
+    ok = None
+    if dist.rank == 0:
+        # tile 0 pasted (same kernels, same homography, same feathering) into a canvas just large enough for it, against the
+        # oracle's three passes (32FC4 copy, warp onto the canvas, feather + accumulate) and its normalise; untimed
+        from oracle import oracle as O
+        vw, vh = (boxes[0][2] + 64) // 64 * 64, boxes[0][3] + 16
+        d_vc, d_vo = ctx.alloc(vw * vh * 16), ctx.alloc(vw * vh * 3)
+        d_vc.zero()
+        ctx.panorama_add(d_img, TW_, TH_, TW_ * 3, d_vc, vw, vh, vw * 16, Ms[0], 300)
+        ctx.panorama_normalize(d_vc, vw, vh, vw * 16, d_vo, vw * 3)
+        want = np.zeros((vh, vw, 4), np.float32)
+        O.panorama_add(tile, want, Ms[0], 300)
+        ok = bool(np.array_equal(d_vc.download((vh, vw, 4), np.float32).view(np.uint32), want.view(np.uint32)) and
+                  np.array_equal(d_vo.download((vh, vw, 3), np.uint8), O.normalize_canvas(want)))
+        d_vc.free(); d_vo.free()
     for d in (d_img, d_canvas, d_out):
         d.free()
     add_ms = ms_add / max(n_add, 1)                      # per paste
@@ -717,7 +753,7 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
     alg_add = TW_ * TH_ * (3 + 32)
     alg_norm = cw * ch * (16 + 3)
     norm_ms = ms_norm / max(n_norm, 1)
-    return {"canvas": [cw, ch], "tiles": 8, "feathering_width": 300,
+    return {"canvas": [cw, ch], "tiles": 8, "feathering_width": 300, "verified_vs_oracle": ok,
             "tile_mpix_per_s": aggregate_rate(dist, 8 * TW_ * TH_ * steps / 1e6, el),
             "step_ms": el / steps * 1e3,
             "add_kernel_ms": add_ms, "box_pixels_per_step": box_px,
@@ -772,6 +808,21 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
     from oracle import oracle as O
     cores = host_cores()
     po = O.lk_params(win=(WIN, WIN), max_level=MAX_LEVEL, max_iters=MAX_ITERS, eps=EPS, flags=0)
+    # -O3 -march=native.  Built here, on the host being timed; used only if it reproduces the portable
+    # build's results bit for bit (same strict float flags, so it does)
+    ref = O.lk_track(frames[0], frames[1], pts, None, po, n_threads=cores)
+    build = "-O2 (portable build)"
+    native = O.build_native()
+    if native:
+        O.use_library(native)
+        try:
+            chk = O.lk_track(frames[0], frames[1], pts, None, po, n_threads=cores)
+            if np.array_equal(chk[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(chk[1], ref[1]):
+                build = "-O3 -march=native, OpenMP, built on this host"
+            else:
+                O.use_library(None)
+        except OSError:
+            O.use_library(None)
     O.lk_track(frames[0], frames[1], pts, None, po, n_threads=cores)          # warm-up
     t0 = time.perf_counter()
     n_pairs = 0
@@ -794,7 +845,7 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
     el1 = time.perf_counter() - t1
     out = {"value": n_pairs * len(pts) / el, "unit": "keypoints/s", "cores": cores, "kind": "port",
            "single_thread_value": n1 * len(pts) / el1, "single_thread_sample": "%d frame pairs, %.1f s" % (n1, el1),
-           "cpu_model": cpu_model(),
+           "cpu_model": cpu_model(), "build": build,
            "sample": "%d frame pairs x %d points of the same stream, oracle dr3o_lk_track (pyramids + Scharr + "
                      "tracker per pair, OpenMP over rows/points), %.1f s" % (n_pairs, len(pts), el)}
     try:                                                 # the real thing, where a cv2 module happens to exist (it does not in this image)
@@ -824,6 +875,7 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
         elw = time.perf_counter() - t0
         out["warp_8uc3_mpix_per_s"] = 12.0 * n_t / elw
         out["warp_sample"] = "%d x one 4000x3000 8UC3 tile, oracle dr3o_warp_perspective, %.2f s" % (n_t, elw)
+    O.use_library(None)
     return out
 
 

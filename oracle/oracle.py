@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdr3oracle.so")
+# DR3O_LIB: the sanitizer build (oracle/libdr3oracle_asan.so) under tests/test_oracle_asan.py
+_LIB_PATH = os.environ.get("DR3O_LIB") or os.path.join(_HERE, "libdr3oracle.so")
 
 # pixel types / flags (mirrors dr3_oracle.h)
 T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
@@ -31,11 +32,36 @@ def build(force=False):
     """Compile the oracle with the committed Makefile (gcc only)."""
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "dr3_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "libdr3oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
 _lib = None
+
+
+def build_native():
+    """-O3 -march=native build for the CPU baseline, made on the host that runs it (the file name carries the CPU model, so a
+    build made elsewhere is never picked up).  Returns its path, or None if it cannot be built here."""
+    import hashlib
+    try:
+        model = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        model = []
+    name = "libdr3oracle_native_%s.so" % hashlib.sha1("".join(model).encode()).hexdigest()[:10]
+    path = os.path.join(_HERE, name)
+    try:
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "dr3_oracle.c")):
+            subprocess.check_call(["make", "-C", _HERE, "NATIVE=" + name, name], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return path
+    except (subprocess.CalledProcessError, OSError):
+        return None
+
+
+def use_library(path=None):
+    """switch the module to another build of the oracle (None = the portable default); the next lib() call loads it"""
+    global _lib, _LIB_PATH
+    _lib = None
+    _LIB_PATH = path or os.environ.get("DR3O_LIB") or os.path.join(_HERE, "libdr3oracle.so")
 
 
 def lib():
@@ -157,6 +183,42 @@ def lk_track(prev, nxt, prev_xy, next_xy0=None, params=None, order=ORDER_RASTER,
     if want_iters:
         return nxt_xy, status, err, r, iters
     return nxt_xy, status, err, r
+
+
+def effective_criteria(p):
+    """TermCriteria clamping of SparsePyrLKOpticalFlowImpl::calc (SURVEY A-3): (max_count, eps)"""
+    mc = min(max(int(p.max_iters), 0), 100) if p.crit_type & 1 else 30
+    eps = min(max(float(p.eps), 0.0), 10.0) if p.crit_type & 2 else 0.01
+    return mc, eps
+
+
+def order_agreement(a, b, params, tol_px=1e-3):
+    """How two runs of the tracker that differ only in the f32 summation order of the window sums agree (a, b = results of
+    lk_track(..., want_iters=True); one of them may come from the GPU with the kernel-order oracle's iteration counts).
+    The bar of BASELINE.json's north_star is 1e-3 px.  It holds for every point that takes the SAME ITERATION PATH in both
+    orders: tracked in both, the same number of Gauss-Newton iterations on every level, below the iteration clamp.  The
+    remainder are points where the last bit of an f32 sum flips an exit test (|delta|^2 <= eps, the oscillation test) or that
+    never converge and run into the clamp; OpenCV's own scalar and SIMD builds differ on those the same way.  They are counted,
+    and those that converged are bounded by one more Gauss-Newton step (2 eps)."""
+    import numpy as _np
+    mc, eps = effective_criteria(params)
+    xy_a, st_a, it_a = a[0], a[1], a[4]
+    xy_b, st_b, it_b = b[0], b[1], b[4]
+    both = (st_a == 1) & (st_b == 1)
+    clamped = both & ((it_a.max(1) >= mc) | (it_b.max(1) >= mc)) if (it_a.shape[1] and mc > 0) else both & False
+    same = both & (it_a == it_b).all(1) & ~clamped
+    flipped = both & ~same & ~clamped
+    with _np.errstate(invalid="ignore"):
+        d = _np.abs(xy_a - xy_b).max(1)
+    return {"tracked_both": int(both.sum()), "status_equal": bool(_np.array_equal(st_a, st_b)),
+            "same_path": int(same.sum()), "same_path_max_dev_px": float(d[same].max()) if same.any() else 0.0,
+            "same_path_within_tol": bool((d[same] <= tol_px).all()) if same.any() else True,
+            "within_tol_frac": float((d[both] <= tol_px).mean()) if both.any() else 1.0,
+            "beyond_tol": int((d[both] > tol_px).sum()),
+            "max_dev_px": float(d[both].max()) if both.any() else 0.0,
+            "exit_flipped": int(flipped.sum()), "exit_flipped_max_dev_px": float(d[flipped].max()) if flipped.any() else 0.0,
+            "clamped": int(clamped.sum()), "clamped_max_dev_px": float(d[clamped].max()) if clamped.any() else 0.0,
+            "eps": eps, "max_count": mc, "tol_px": tol_px}
 
 
 def halfsample(img, mode=HALF_TRUNC):

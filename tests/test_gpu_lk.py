@@ -1,16 +1,16 @@
 """HIP Lucas-Kanade tracker vs the oracle.
 
-Bar: integer/logic path bit-exact -- checked by running the oracle in the kernel's own float
-summation order (ORDER_WAVE64) and demanding identical bits for positions, status, err and
-iteration counts; and <= 1e-3 px against the oracle in OpenCV's scalar raster order, the tolerance
-BASELINE.json's north_star states for tracked (u,v).
-
-Why the second bar is a fraction and not 100 %: the window sums are f32 and their value depends on
-the summation order (OpenCV's own scalar and SIMD builds differ the same way).  A last-bit change
-in b1/b2 can flip the |delta|^2 <= eps exit test of one iteration, which moves that point by about
-one more Gauss-Newton step (~5e-3 px at eps = 0.01).  On the 2000-point KITTI-shaped case exactly
-1 point does so (oracle raster order vs oracle wave order, measured on the CPU alone), so the bar
-is: >= 99.8 % of the tracked points within 1e-3 px and no point beyond 0.05 px."""
+Bar 1: integer/logic path bit-exact -- checked by running the oracle in the kernel's own float summation order
+(ORDER_WAVE64) and demanding identical bits for positions, status and err.
+Bar 2: <= 1e-3 px against the oracle in OpenCV's scalar raster order, the tolerance BASELINE.json's north_star states for
+tracked (u,v).  The window sums are f32 and their value depends on the summation order (OpenCV's own scalar and SIMD builds
+differ the same way), so bar 2 is stated the way tests/test_gpu_kitti.py states it (oracle.order_agreement): EVERY point that
+takes the same iteration path in both orders -- tracked in both, the same number of Gauss-Newton iterations on every level,
+below the iteration clamp -- agrees within 1e-3 px.  The remainder is counted and bounded: a point where the last bit of a
+sum flips an exit test takes one more (or one fewer) Gauss-Newton step of at most eps, so it stays within 2 eps; points that
+run into the iteration clamp never converged in either order and are only counted.  Points beyond 1e-3 px -- all of them
+from that remainder -- are at most 1 % of the tracked points (measured: 1 of 1972 on the 2000-point KITTI-shaped case, the
+largest exit-flip deviation 5.8e-3 px)."""
 import ctypes as C
 
 import numpy as np
@@ -21,21 +21,21 @@ pytestmark = pytest.mark.gpu
 TOL_PX = 1e-3   # north_star: "tracked sub-pixel (u,v) ... within 1e-3 px"
 
 
-def _check_pair(dr3, O, ctx, A, B, pts, p_gpu, p_orc, next0=None, frac_tol=0.998, max_dev=0.05):
+def _check_pair(dr3, O, ctx, A, B, pts, p_gpu, p_orc, next0=None):
     g_xy, g_st, g_err, g_L = ctx.calcOpticalFlowPyrLK(A, B, pts, next0, p_gpu)
-    w_xy, w_st, w_err, w_L = O.lk_track(A, B, pts, next0, p_orc, order=O.ORDER_WAVE64)
-    r_xy, r_st, r_err, r_L = O.lk_track(A, B, pts, next0, p_orc, order=O.ORDER_RASTER)
+    w_xy, w_st, w_err, w_L, w_it = O.lk_track(A, B, pts, next0, p_orc, order=O.ORDER_WAVE64, want_iters=True)
+    r_xy, r_st, r_err, r_L, r_it = O.lk_track(A, B, pts, next0, p_orc, order=O.ORDER_RASTER, want_iters=True)
     assert g_L == w_L == r_L
-    # bit-exact against the oracle run in the kernel's summation order
+    # bar 1: bit-exact against the oracle run in the kernel's summation order
     assert np.array_equal(g_st, w_st)
     assert np.array_equal(g_xy.view(np.uint32), w_xy.view(np.uint32)), np.abs(g_xy - w_xy).max()
     assert np.array_equal(g_err.view(np.uint32), w_err.view(np.uint32))
-    # within tolerance of the raster-order oracle (what OpenCV's scalar path computes)
-    both = (g_st == 1) & (r_st == 1)
-    d = np.abs(g_xy - r_xy)[both]
-    if d.size:
-        assert (d <= TOL_PX).mean() >= frac_tol, (d.max(), (d > TOL_PX).sum())
-        assert d.max() <= max_dev, d.max()
+    # bar 2: the raster-order oracle (what OpenCV's scalar path computes); the GPU's iteration counts are the kernel-order
+    # oracle's (test_batch_track_* compare them bit for bit)
+    ag = O.order_agreement((g_xy, g_st, g_err, g_L, w_it), (r_xy, r_st, r_err, r_L, r_it), p_orc, TOL_PX)
+    assert ag["same_path_within_tol"], ag
+    assert ag["beyond_tol"] <= max(2, 0.01 * ag["tracked_both"]), ag              # all of them exit flips or clamped points
+    assert ag["exit_flipped_max_dev_px"] <= max(2 * ag["eps"], 2 * TOL_PX), ag
     return g_xy, g_st, g_err, r_xy, r_st
 
 
@@ -137,7 +137,7 @@ def test_window_shapes(dr3, O, synth, ctx, win):
     A, B, T = synth.frame_pair(400, 300)
     pts = synth.grid_points(400, 300, 40)
     pg, po = _params(dr3, O, win=win, max_level=3, max_iters=20, eps=0.01)
-    _check_pair(dr3, O, ctx, A, B, pts, pg, po, frac_tol=0.99, max_dev=0.25)
+    _check_pair(dr3, O, ctx, A, B, pts, pg, po)
 
 
 def test_points_on_and_beyond_borders(dr3, O, synth, ctx):
@@ -149,7 +149,7 @@ def test_points_on_and_beyond_borders(dr3, O, synth, ctx):
                     [-5, 50], [w + 40, 20], [50, -30.5], [50, h + 25], [-100, -100], [10.75, 10.5],
                     [w - 11, h - 11], [7.9, 7.9]], np.float32)
     pg, po = _params(dr3, O, win=(15, 15), max_level=3, max_iters=30, eps=0.01)
-    g_xy, g_st, *_ = _check_pair(dr3, O, ctx, A, B, pts, pg, po, frac_tol=0.9, max_dev=0.5)
+    g_xy, g_st, *_ = _check_pair(dr3, O, ctx, A, B, pts, pg, po)
     assert g_st[10] == 0                      # far outside: lost
 
 
@@ -234,7 +234,7 @@ def test_flags_initial_flow_and_min_eigenvals(dr3, O, synth, ctx):
     guess = (synth.apply_T(T, pts) + 0.7).astype(np.float32)
     for flags in (dr3.LK_USE_INITIAL_FLOW, dr3.LK_GET_MIN_EIGENVALS, dr3.LK_USE_INITIAL_FLOW | dr3.LK_GET_MIN_EIGENVALS):
         pg, po = _params(dr3, O, win=(15, 15), max_level=2, flags=flags)
-        _check_pair(dr3, O, ctx, A, B, pts, pg, po, next0=guess.copy(), frac_tol=0.99, max_dev=0.25)
+        _check_pair(dr3, O, ctx, A, B, pts, pg, po, next0=guess.copy())
 
 
 def test_criteria_clamping(dr3, O, synth, ctx):
@@ -243,7 +243,7 @@ def test_criteria_clamping(dr3, O, synth, ctx):
     pts = synth.grid_points(320, 200, 40)
     for crit, iters, eps in [(1, 5, 0.0), (2, 0, 0.03), (0, 7, 7.0), (3, 1000, 1e-3), (3, -4, 0.01), (3, 10, 50.0), (3, 0, 0.01)]:
         pg, po = _params(dr3, O, win=(13, 13), max_level=2, max_iters=iters, eps=eps, crit_type=crit)
-        _check_pair(dr3, O, ctx, A, B, pts, pg, po, frac_tol=0.98, max_dev=0.5)
+        _check_pair(dr3, O, ctx, A, B, pts, pg, po)
 
 
 def test_empty_point_set(dr3, ctx, synth):

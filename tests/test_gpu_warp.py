@@ -78,6 +78,32 @@ def test_warp_large_tile_random_homographies(dr3, O, ctx, synth):
         assert np.array_equal(ctx.warpPerspective(src, M, (1500, 1100)), O.warp_perspective(src, M, (1500, 1100))), k
 
 
+def test_config3_tiles_at_their_own_size_4000x3000(dr3, O, ctx, synth):
+    """BASELINE configs[2] at its own size: one 4000x3000 tile as 8UC3 and one as the reference's 32FC4 form
+    (src/panorama.cpp:178-192), each through its configs[2] homography (synth.tile_homography, shifted as bench.py shifts it),
+    bit-exact against the oracle.  The guarded fast coordinate path is enabled per job from the coordinate magnitudes
+    (warp_fast_coords_ok), so the size itself is part of what is checked; 12 Mpix put ~6000 pixels through the tie guard."""
+    rng = np.random.default_rng(3)
+    TW, TH = 4000, 3000
+    low = rng.integers(0, 256, (TH // 4, TW // 4, 3), dtype=np.uint8)
+    src = np.repeat(np.repeat(low, 4, axis=0), 4, axis=1)
+    src ^= rng.integers(0, 32, (TH, TW, 1), dtype=np.uint8)                       # fine detail on top of the blocks
+    for i in (0, 5):
+        M = synth.tile_homography(i, TW, TH)
+        M[0, 2] -= 60.0; M[1, 2] -= 60.0
+        got = ctx.warpPerspective(src, M, (TW, TH))
+        want = O.warp_perspective(src, M, (TW, TH))
+        assert np.array_equal(got, want), (i, int((got != want).sum()))
+        assert (got != 0).mean() > 0.9                                            # the tile really lands inside its canvas
+    src4 = np.ones((TH, TW, 4), np.float32)
+    src4[..., :3] = src
+    M = synth.tile_homography(2, TW, TH)
+    M[0, 2] -= 60.0; M[1, 2] -= 60.0
+    got = ctx.warpPerspective(src4, M, (TW, TH))
+    want = O.warp_perspective(src4, M, (TW, TH))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_warp_small_and_degenerate(dr3, O, ctx):
     """dst smaller than one 16x64 block, singular-ish / far-outside maps -> zeros like the oracle"""
     rng = np.random.default_rng(4)
