@@ -414,6 +414,11 @@ def main(argv=None):
     if not args.no_frontend:
         frontend = frontend_leg(dist, ctx, dr3, batch, B, sync, max(3, min(args.steps, 10)))
 
+    # ---- the tracker's other instantiations: the reference's own literals and configs[0] ---------------------
+    lk_other = None
+    if args.workload == "kitti" and not args.no_frontend:
+        lk_other = lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu)
+
     # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------
     warp = None
     if not args.no_warp:
@@ -488,6 +493,7 @@ def main(argv=None):
             "hbm_copy_measured_GBps": copy_gbps,
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,
+            "lk_other_windows": lk_other,
             "warp": warp,
             "ref_pyramid_bcast": ref_bcast,
             "cpu_baseline": cpu,
@@ -540,6 +546,57 @@ def frontend_leg(dist, ctx, dr3, batch, B, sync, steps):
                        "Shi-Tomasi (cell 15), LK %dx%d / %d levels from the detected corners" % (B, WIN, WIN, MAX_LEVEL + 1)}
     for d in (d_pts, d_next, d_st, d_err):
         d.free()
+    return out
+
+
+def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
+    """The tracker at the parameters the reference's call site really passes (src/initialization.cpp:593-613: 30x30 window,
+    maxLevel 4 -> 3 at this size, 1000 -> 100 iterations, eps 1e-3, USE_INITIAL_FLOW with the identity guess of :578), which
+    runs the generic four-pass kernel, and at BASELINE configs[0] (21x21, 3 levels, ~500 corners), the compile-time two-pass
+    kernel; 128 pairs x 546 grid corners per launch, resident inputs, kernel time from HIP events, pair 0 against the oracle.
+    Untimed extras beside the headline metric."""
+    W_, H_, NP = len(frames[0][0]), len(frames[0]), 128
+    pts = synth.grid_points(W_, H_, 30)
+    n = len(pts)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (NP, n, 2)), np.float32)
+    out = {}
+    cases = (("reference_literals_30x30", dict(win=(30, 30), max_level=4, max_iters=1000, eps=1e-3, flags=dr3.LK_USE_INITIAL_FLOW if have_gpu else 4),
+              "lk_track_kernel<4, 0>"),
+             ("configs0_21x21_3_levels", dict(win=(21, 21), max_level=2, max_iters=30, eps=0.01, flags=0), "lk_track_kernel<2, 21>"))
+    for name, kw, kernel in cases:
+        b = dr3.FrameBatch(ctx, W_, H_, win=kw["win"], max_level=kw["max_level"], capacity=NP + 1)
+        for s0 in range(0, NP + 1, 64):
+            b.upload(s0, np.stack(frames[s0:s0 + 64]))
+        b.build(0, NP + 1, True)
+        d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+        d_st, d_err = ctx.alloc(NP * n), ctx.alloc(NP * n * 4)
+        params = dr3.lk_params(**kw)
+        ctx.profile_enable(True)
+        for _ in range(2):
+            d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params)
+        sync(); ctx.profile_reset()
+        reps = 5
+        for _ in range(reps):
+            d_next.upload(P)                              # USE_INITIAL_FLOW reads next_xy: every launch starts from the identity guess
+            b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params)
+        sync()
+        ms, cnt = ctx.profile_read(dr3.PROF_LK)
+        ctx.profile_enable(False)
+        ok = None
+        if dist.rank == 0 and have_gpu:
+            from oracle import oracle as O
+            po = O.lk_params(**kw)
+            o = O.lk_track(frames[0], frames[1], pts, pts.copy() if kw["flags"] & 4 else None, po, order=O.ORDER_WAVE64)
+            g_xy = d_next.download((NP, n, 2), np.float32)[0]; g_st = d_st.download((NP, n), np.uint8)[0]
+            ok = bool(np.array_equal(g_xy.view(np.uint32), o[0].view(np.uint32)) and np.array_equal(g_st, o[1]) and
+                      np.array_equal(d_err.download((NP, n), np.float32)[0].view(np.uint32), o[2].view(np.uint32)))
+        k_ms = ms / max(cnt, 1)
+        out[name] = {"kernel": kernel, "levels": b.levels, "pairs_per_launch": NP, "points_per_pair": n, "kernel_ms": k_ms,
+                     "keypoints_per_sec_kernel_only": NP * n / (k_ms * 1e-3), "tracked_fraction": float(d_st.download((NP, n), np.uint8).mean()),
+                     "verified_vs_oracle": ok}
+        for d in (d_prev, d_next, d_st, d_err):
+            d.free()
+        b.close()
     return out
 
 

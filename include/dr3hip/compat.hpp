@@ -12,9 +12,11 @@
 //     Stitch::process after align_pair  src/stitch.cpp:33-80       -> dr3hip::stitch_compose
 //     Panorama::paste_images / add_img_to_canvas / normalize_canvas  src/panorama.cpp:143-229
 //                                                                 -> dr3hip::WeightedCanvas
-// Images travel as MatView {data, rows, cols, step, type}: a plain view that a cv::Mat converts to
-// with MatView::of(mat) where OpenCV exists (define DR3HIP_WITH_OPENCV before including), so
-// include/features.hpp, include/stitch.hpp and include/panorama.hpp of the reference stay untouched.
+// Without OpenCV images travel as MatView {data, rows, cols, step, type} and outputs as dr3hip::Image.  With
+// DR3HIP_WITH_OPENCV defined before including (the reference's build) every call above also exists with OpenCV's own
+// argument types -- const cv::Mat&, cv::Mat& dst, std::vector<cv::Point2f>&, cv::Size, cv::TermCriteria, a cv::Mat M --
+// so the reference's call expressions change by namespace ONLY (cv:: / utils:: -> dr3hip::), with no cast and no copy at the
+// call site; include/features.hpp, include/stitch.hpp and include/panorama.hpp of the reference stay untouched.
 // Error behaviour mirrors OpenCV's: bad arguments / device errors throw (dr3hip::Error instead of
 // cv::Exception); per-point tracking failure is reported through status[i] == 0 only.
 #ifndef DR3HIP_COMPAT_HPP
@@ -112,6 +114,38 @@ private:
     dr3hip_ctx* ctx_; int device_;
 };
 
+namespace detail {
+// the tracker call shared by the MatView and the cv-typed front ends; PointT is any { float x, y; } pair
+template <class PointT>
+inline int lk_call(const MatView& prevImg, const MatView& nextImg, const std::vector<PointT>& prevPts, std::vector<PointT>& nextPts,
+                   std::vector<unsigned char>& status, std::vector<float>& err, int win_w, int win_h, int maxLevel,
+                   int crit_type, int crit_count, double crit_eps, int flags, double minEigThreshold, int device)
+{
+    static_assert(sizeof(PointT) == 2 * sizeof(float), "a point must be two packed floats (x, y)");
+    if (prevImg.empty() || nextImg.empty() || prevImg.type != DR3HIP_8UC1 || nextImg.type != DR3HIP_8UC1 ||
+        prevImg.rows != nextImg.rows || prevImg.cols != nextImg.cols)
+        throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: 8-bit single-channel images of equal size expected");
+    const std::size_t n = prevPts.size();
+    if (flags & 4 /* OPTFLOW_USE_INITIAL_FLOW */) {
+        if (nextPts.size() != n) throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: nextPts.size() != prevPts.size() with USE_INITIAL_FLOW");
+    } else {
+        nextPts.resize(n);
+    }
+    status.assign(n, 1);
+    err.assign(n, 0.f);
+    dr3hip_lk_params p;
+    p.win_w = win_w; p.win_h = win_h; p.max_level = maxLevel;
+    p.crit_type = crit_type; p.max_iters = crit_count; p.eps = crit_eps;
+    p.flags = flags; p.min_eig_threshold = minEigThreshold;
+    Context& c = Context::instance(device);
+    return c.check(dr3hip_lk_track(c.get(), static_cast<const uint8_t*>(prevImg.data), static_cast<const uint8_t*>(nextImg.data),
+                                   prevImg.cols, prevImg.rows, (int)prevImg.step, (int)nextImg.step,
+                                   n ? &prevPts[0].x : nullptr, n ? &nextPts[0].x : nullptr, (int)n,
+                                   n ? status.data() : nullptr, n ? err.data() : nullptr, &p),
+                   "calcOpticalFlowPyrLK");
+}
+}  // namespace detail
+
 // cv::calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, status, err, winSize, maxLevel,
 //                          criteria, flags, minEigThreshold)
 inline int calcOpticalFlowPyrLK(const MatView& prevImg, const MatView& nextImg,
@@ -121,28 +155,8 @@ inline int calcOpticalFlowPyrLK(const MatView& prevImg, const MatView& nextImg,
                                 TermCriteria criteria = TermCriteria(), int flags = 0,
                                 double minEigThreshold = 1e-4, int device = 0)
 {
-    if (prevImg.empty() || nextImg.empty() || prevImg.type != DR3HIP_8UC1 || nextImg.type != DR3HIP_8UC1 ||
-        prevImg.rows != nextImg.rows || prevImg.cols != nextImg.cols)
-        throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: 8-bit single-channel images of equal size expected");
-    const std::size_t n = prevPts.size();
-    if (flags & OPTFLOW_USE_INITIAL_FLOW) {
-        if (nextPts.size() != n) throw Error(DR3HIP_EINVAL, "calcOpticalFlowPyrLK: nextPts.size() != prevPts.size() with USE_INITIAL_FLOW");
-    } else {
-        nextPts.resize(n);
-    }
-    status.assign(n, 1);
-    err.assign(n, 0.f);
-    dr3hip_lk_params p;
-    p.win_w = winSize.width; p.win_h = winSize.height; p.max_level = maxLevel;
-    p.crit_type = criteria.type; p.max_iters = criteria.maxCount; p.eps = criteria.epsilon;
-    p.flags = flags; p.min_eig_threshold = minEigThreshold;
-    Context& c = Context::instance(device);
-    static_assert(sizeof(Point2f) == 2 * sizeof(float), "Point2f must be two packed floats");
-    return c.check(dr3hip_lk_track(c.get(), static_cast<const uint8_t*>(prevImg.data), static_cast<const uint8_t*>(nextImg.data),
-                                   prevImg.cols, prevImg.rows, (int)prevImg.step, (int)nextImg.step,
-                                   n ? &prevPts[0].x : nullptr, n ? &nextPts[0].x : nullptr, (int)n,
-                                   n ? status.data() : nullptr, n ? err.data() : nullptr, &p),
-                   "calcOpticalFlowPyrLK");
+    return detail::lk_call(prevImg, nextImg, prevPts, nextPts, status, err, winSize.width, winSize.height, maxLevel,
+                           criteria.type, criteria.maxCount, criteria.epsilon, flags, minEigThreshold, device);
 }
 
 // cv::warpPerspective(src, dst, M, dsize, flags = INTER_LINEAR, BORDER_CONSTANT, 0); M: 3x3 f32 row-major
@@ -320,6 +334,122 @@ private:
     WeightedCanvas(const WeightedCanvas&); WeightedCanvas& operator=(const WeightedCanvas&);
     Context& c_; int W_, H_; float* canvas_;
 };
+
+#ifdef DR3HIP_WITH_OPENCV
+// =====================================================================================================================
+// OpenCV-typed front ends: the reference's call expressions with `cv::` (or `utils::`) replaced by `dr3hip::`, nothing else.
+//   src/initialization.cpp:608-613   dr3hip::calcOpticalFlowPyrLK(frame_ref->_img_pyr[0], frame_cur->_img_pyr[0], _kps_ref, _kps_cur,
+//                                        status, error, cv::Size2i(klt_win_size, klt_win_size), 4, termcrit, cv::OPTFLOW_USE_INITIAL_FLOW);
+//   src/stitch.cpp:73-74             dr3hip::warpPerspective(_right_img, warped_right_image, translate_top_left_mat * Hinv, {new_width, new_height});
+//   src/panorama.cpp:192             dr3hip::warpPerspective(weighted_img, warped_img, M, this->get_final_size(), CV_INTER_LINEAR);
+//   src/utils.cpp:191                dr3hip::remap(img, warped, u, v, CV_INTER_LINEAR);
+//   src/frame.cpp:18                 dr3hip::create_img_pyramid(img, Config::n_pyr_levels(), _img_pyr);
+//   src/utils.cpp:196-201, :267-272  dr3hip::warp_spherical(img, f) / dr3hip::warp_cylindrical(img, f)
+// Outputs are created like OpenCV creates them (dst.create(dsize, src.type())); the kernels write straight into them.
+// =====================================================================================================================
+inline void calcOpticalFlowPyrLK(const cv::Mat& prevImg, const cv::Mat& nextImg,
+                                 const std::vector<cv::Point2f>& prevPts, std::vector<cv::Point2f>& nextPts,
+                                 std::vector<unsigned char>& status, std::vector<float>& err,
+                                 cv::Size winSize = cv::Size(21, 21), int maxLevel = 3,
+                                 cv::TermCriteria criteria = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30, 0.01),
+                                 int flags = 0, double minEigThreshold = 1e-4)
+{
+    detail::lk_call(MatView::of(prevImg), MatView::of(nextImg), prevPts, nextPts, status, err, winSize.width, winSize.height, maxLevel,
+                    criteria.type, criteria.maxCount, criteria.epsilon, flags, minEigThreshold, 0);
+}
+
+namespace detail {
+// the 3x3 matrix as the f32 values the C ABI takes.  The reference passes CV_32F (src/stitch.cpp:71-74, src/panorama.cpp:148);
+// CV_64F is accepted when every entry is exactly a float (OpenCV itself widens M to double, so nothing is lost either way).
+inline void mat3x3_f32(const cv::Mat& M, float out[9])
+{
+    if (M.rows != 3 || M.cols != 3 || (M.type() != CV_32FC1 && M.type() != CV_64FC1))
+        throw Error(DR3HIP_EINVAL, "warpPerspective: M must be a 3x3 CV_32F or CV_64F matrix");
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            if (M.type() == CV_32FC1) out[3 * r + c] = M.ptr<float>(r)[c];
+            else {
+                const double v = M.ptr<double>(r)[c];
+                out[3 * r + c] = static_cast<float>(v);
+                if (static_cast<double>(out[3 * r + c]) != v && v == v)
+                    throw Error(DR3HIP_EINVAL, "warpPerspective: CV_64F matrix entry is not representable in f32 (the C ABI takes the f32 matrix the reference passes)");
+            }
+        }
+}
+}  // namespace detail
+
+inline void warpPerspective(const cv::Mat& src, cv::Mat& dst, const cv::Mat& M, cv::Size dsize, int flags = 1 /* cv::INTER_LINEAR */)
+{
+    if (src.empty()) throw Error(DR3HIP_EINVAL, "warpPerspective: empty source");
+    if ((flags & 7) != INTER_LINEAR) throw Error(DR3HIP_EINVAL, "warpPerspective: only INTER_LINEAR is implemented (the reference uses no other)");
+    float m[9];
+    detail::mat3x3_f32(M, m);
+    const MatView s = MatView::of(src);
+    cv::Mat out;                                                         // src and dst may be the same Mat: warp into a fresh one
+    out.create(dsize.height > 0 ? dsize.height : src.rows, dsize.width > 0 ? dsize.width : src.cols, src.type());
+    Context& c = Context::instance(0);
+    c.check(dr3hip_warp_perspective(c.get(), s.data, s.cols, s.rows, (int)s.step, s.type, out.data, out.cols, out.rows, (int)out.step, m,
+                                    (flags & WARP_INVERSE_MAP) ? DR3HIP_WARP_INVERSE_MAP : 0), "warpPerspective");
+    dst = out;
+}
+
+inline void remap(const cv::Mat& src, cv::Mat& dst, const cv::Mat& map1, const cv::Mat& map2, int interpolation)
+{
+    if (interpolation != INTER_LINEAR) throw Error(DR3HIP_EINVAL, "remap: only INTER_LINEAR is implemented");
+    const MatView s = MatView::of(src), m1 = MatView::of(map1), m2 = MatView::of(map2);
+    if (s.empty() || m1.empty() || m2.empty() || m1.type != DR3HIP_32FC1 || m2.type != DR3HIP_32FC1 ||
+        m1.rows != m2.rows || m1.cols != m2.cols || m1.step != m2.step)
+        throw Error(DR3HIP_EINVAL, "remap: CV_32FC1 maps of equal size expected");
+    cv::Mat out;
+    out.create(map1.rows, map1.cols, src.type());
+    Context& c = Context::instance(0);
+    c.check(dr3hip_remap_bilinear(c.get(), s.data, s.cols, s.rows, (int)s.step, s.type, out.data, out.cols, out.rows, (int)out.step,
+                                  static_cast<const float*>(m1.data), static_cast<const float*>(m2.data), (int)m1.step), "remap");
+    dst = out;
+}
+
+// utils::create_img_pyramid(img_lvl_0, n_levels, pyr) with ImgPyramid = std::vector<cv::Mat> (include/frame.hpp:17): level 0
+// shares the caller's pixels exactly as src/utils.cpp:423 does, levels 1.. are new CV_8U images of floor-halved size
+inline void create_img_pyramid(const cv::Mat& img_lvl_0, int n_levels, std::vector<cv::Mat>& pyr, int mode = DR3HIP_HALF_REF_X86)
+{
+    const MatView v0 = MatView::of(img_lvl_0);
+    if (v0.empty() || v0.type != DR3HIP_8UC1 || n_levels < 1)
+        throw Error(DR3HIP_EINVAL, "create_img_pyramid: 8-bit gray image and n_levels >= 1 expected");
+    pyr.resize((std::size_t)n_levels);
+    pyr[0] = img_lvl_0;
+    std::vector<uint8_t*> ptrs((std::size_t)n_levels, nullptr);
+    std::vector<int> strides((std::size_t)n_levels, 0);
+    for (int l = 1; l < n_levels; ++l) {
+        if (pyr[l - 1].rows / 2 == 0 || pyr[l - 1].cols / 2 == 0) throw Error(DR3HIP_EINVAL, "create_img_pyramid: too many levels for this image");
+        pyr[l] = cv::Mat(pyr[l - 1].rows / 2, pyr[l - 1].cols / 2, CV_8UC1);
+        ptrs[l] = pyr[l].data; strides[l] = (int)pyr[l].step;
+    }
+    Context& c = Context::instance(0);
+    c.check(dr3hip_halfsample_pyramid(c.get(), static_cast<const uint8_t*>(v0.data), v0.cols, v0.rows, (int)v0.step, n_levels, mode,
+                                      ptrs.data(), strides.data()), "create_img_pyramid");
+}
+
+inline cv::Mat warp_spherical(cv::Mat img, float f)
+{
+    const MatView s = MatView::of(img);
+    if (s.empty()) throw Error(DR3HIP_EINVAL, "warp_spherical: empty image");
+    cv::Mat warped;
+    warped.create(img.rows, img.cols, img.type());
+    Context& c = Context::instance(0);
+    c.check(dr3hip_warp_local(c.get(), s.data, s.cols, s.rows, (int)s.step, s.type, warped.data, (int)warped.step, DR3HIP_WARP_SPHERICAL, f), "warp_spherical");
+    return warped;
+}
+inline cv::Mat warp_cylindrical(cv::Mat img, float f)
+{
+    const MatView s = MatView::of(img);
+    if (s.empty()) throw Error(DR3HIP_EINVAL, "warp_cylindrical: empty image");
+    cv::Mat warped;
+    warped.create(img.rows, img.cols, img.type());
+    Context& c = Context::instance(0);
+    c.check(dr3hip_warp_local(c.get(), s.data, s.cols, s.rows, (int)s.step, s.type, warped.data, (int)warped.step, DR3HIP_WARP_CYLINDRICAL, f), "warp_cylindrical");
+    return warped;
+}
+#endif  // DR3HIP_WITH_OPENCV
 
 }  // namespace dr3hip
 #endif  // DR3HIP_COMPAT_HPP
