@@ -119,6 +119,9 @@ def _signatures():
         "dr3hip_batch_detect": ([vp, ip, ip, ip, ip, ip, C.c_double, ip, vp, vp], ip),
         "dr3hip_fast_score_map": ([vp, vp, ip, ip, ip, ip, vp], ip),
         "dr3hip_check_fundamental": ([vp, vp, ip, vp, vp, ip, C.c_float, vp, vp], ip),
+        "dr3hip_check_fundamental_dev": ([vp, vp, ip, vp, vp, vp, ip, C.c_float, vp, vp], ip),
+        "dr3hip_normalize_points": ([vp, vp, ip, vp, vp], ip),
+        "dr3hip_normalize_points_dev": ([vp, vp, vp, ip, ip, vp, vp], ip),
         "dr3hip_warp_local": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_warp_local_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, C.c_float], ip),
         "dr3hip_stitch_geometry": ([vp, ip, ip, vp, vp, vp, P(ip), P(ip)], ip),
@@ -290,6 +293,23 @@ class Context:
         self._chk(lib().dr3hip_check_fundamental(self.h, _p(F), len(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(scores),
                                                  None if inl is None else _p(inl)))
         return scores, inl
+
+    def check_fundamental_dev(self, d_F21, n_hyp, d_pts1, d_pts2, d_mask, n, sigma, d_scores, d_inliers=None):
+        """device-resident CheckFundamental (d_* = DeviceBuffer or raw pointers); enqueued, call sync() to wait"""
+        ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        self._chk(lib().dr3hip_check_fundamental_dev(self.h, ptr(d_F21), int(n_hyp), ptr(d_pts1), ptr(d_pts2), ptr(d_mask), int(n),
+                                                     C.c_float(sigma), ptr(d_scores), ptr(d_inliers)))
+
+    def normalize_points(self, xy):
+        """InitHelper::Normalize (src/initialization.cpp:365-410) -> (normalised points (n,2) f32, T (3,3) f32)"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(xy); T = np.zeros(9, np.float32)
+        self._chk(lib().dr3hip_normalize_points(self.h, _p(xy), len(xy), _p(out), _p(T)))
+        return out, T.reshape(3, 3)
+
+    def normalize_points_dev(self, d_xy, d_mask, n, n_sets, d_out_xy, d_T):
+        ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        self._chk(lib().dr3hip_normalize_points_dev(self.h, ptr(d_xy), ptr(d_mask), int(n), int(n_sets), ptr(d_out_xy), ptr(d_T)))
 
     def stitch_compose(self, left, right, H, alpha=0.5, beta=0.5, gamma=0.0):
         """Stitch::process after align_pair (src/stitch.cpp:33-80): geometry on the host, both warps and the addWeighted

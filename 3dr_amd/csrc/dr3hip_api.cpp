@@ -471,6 +471,7 @@ int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const
         HIPCHK(ctx, hipMemcpyAsync(dp + pb, pts2, pb, hipMemcpyHostToDevice, ctx->stream));
     }
     CheckFArgs a;
+    a.mask = nullptr;
     a.F = (const float*)ctx->stage[0].p; a.n_hyp = n_hyp;
     a.pts1 = (const float*)dp; a.pts2 = (const float*)(dp + pb); a.n = n;
     a.inv_sigma_square = (float)(1.0 / (double)(sigma * sigma));          // const float invSigmaSquare = 1.0/(sigma*sigma) (:190)
@@ -478,6 +479,56 @@ int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const
     HIPCHK(ctx, launch_check_fundamental(a, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(scores, a.scores, sb, hipMemcpyDeviceToHost, ctx->stream));
     if (ib && n) HIPCHK(ctx, hipMemcpyAsync(inliers, a.inliers, ib, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_check_fundamental_dev(dr3hip_ctx* ctx, const float* d_F21, int n_hyp, const float* d_pts1, const float* d_pts2,
+                                 const uint8_t* d_mask, int n, float sigma, float* d_scores, uint8_t* d_inliers)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_F21 || !d_pts1 || !d_pts2 || !d_scores || n_hyp < 1 || n < 0 || n_hyp > (1 << 20) || n > (1 << 24))
+        return fail(ctx, DR3HIP_EINVAL, "check_fundamental_dev: bad arguments");
+    DeviceGuard g(ctx->device);
+    CheckFArgs a;
+    a.F = d_F21; a.n_hyp = n_hyp; a.mask = d_mask;
+    a.pts1 = d_pts1; a.pts2 = d_pts2; a.n = n;
+    a.inv_sigma_square = (float)(1.0 / (double)(sigma * sigma));
+    a.scores = d_scores; a.inliers = d_inliers;
+    HIPCHK(ctx, launch_check_fundamental(a, ctx->stream));
+    return DR3HIP_OK;
+}
+
+// ---- InitHelper::Normalize --------------------------------------------------------------------------
+int dr3hip_normalize_points_dev(dr3hip_ctx* ctx, const float* d_xy, const uint8_t* d_mask, int n, int n_sets,
+                                float* d_out_xy, float* d_T)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_xy || !d_out_xy || !d_T || n < 0 || n_sets < 0 || n > (1 << 24))
+        return fail(ctx, DR3HIP_EINVAL, "normalize_points_dev: bad arguments");
+    if (n_sets == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    NormArgs a;
+    a.xy = d_xy; a.xy_step = 2ll * n; a.mask = d_mask; a.mask_step = n; a.n = n; a.n_sets = n_sets;
+    a.out_xy = d_out_xy; a.T = d_T;
+    HIPCHK(ctx, launch_normalize_points(a, ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_normalize_points(dr3hip_ctx* ctx, const float* xy, int n, float* out_xy, float T[9])
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!xy || !out_xy || !T || n < 0 || n > (1 << 24)) return fail(ctx, DR3HIP_EINVAL, "normalize_points: bad arguments");
+    DeviceGuard g(ctx->device);
+    const size_t pb = sizeof(float) * 2 * (size_t)(n ? n : 1);
+    int rc;
+    if ((rc = stage_reserve(ctx, 2, 2 * pb + 256)) || (rc = stage_reserve(ctx, 3, 256))) return rc;
+    uint8_t* dp = (uint8_t*)ctx->stage[2].p;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(dp, xy, pb, hipMemcpyHostToDevice, ctx->stream));
+    rc = dr3hip_normalize_points_dev(ctx, (const float*)dp, nullptr, n, 1, (float*)(dp + pb), (float*)ctx->stage[3].p);
+    if (rc) return rc;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(out_xy, dp + pb, pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(T, ctx->stage[3].p, 9 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return DR3HIP_OK;
 }

@@ -108,8 +108,17 @@ struct FastArgs {          // FAST-10 score map + grid-best selection of one pyr
     int n_cells;                                  // cells (and occupancy bytes) per frame
 };
 
+struct NormArgs {          // InitHelper::Normalize for n_sets point sets (fast_kernels.hip)
+    const float* xy; long long xy_step;           // set k: n points (x, y) at xy + k * xy_step floats
+    const uint8_t* mask; long long mask_step;     // optional: 0 = the point was erased (lost by the tracker); bytes between sets
+    int n, n_sets;
+    float* out_xy;                                // same layout as xy
+    float* T;                                     // n_sets x 9
+};
+
 struct CheckFArgs {        // InitHelper::CheckFundamental for n_hyp matrices (fast_kernels.hip)
     const float* F; int n_hyp;                    // n_hyp x 9, row-major
+    const uint8_t* mask;                          // optional (device entry point): matches with mask 0 were erased, they are skipped
     const float* pts1; const float* pts2; int n;  // n x 2 each
     float inv_sigma_square;
     float* scores;                                // n_hyp
@@ -153,6 +162,7 @@ hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
+hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);

@@ -241,6 +241,10 @@ __global__ __launch_bounds__(64) void check_fundamental_kernel(const CheckFArgs 
     const float th = 3.841f, thScore = 5.991f, inv = a.inv_sigma_square;
     float score = 0.f;
     for (int i = 0; i < a.n; ++i) {
+        if (a.mask && !a.mask[i]) {                // erased match (wave-uniform): contributes nothing, as if it were not in the vectors
+            if (a.inliers) a.inliers[(long long)hyp * a.n + i] = 0;
+            continue;
+        }
         const float u1 = a.pts1[2 * i], v1 = a.pts1[2 * i + 1], u2 = a.pts2[2 * i], v2 = a.pts2[2 * i + 1];
         bool in = true;
         const float a2 = f11 * u1 + f12 * v1 + f13, b2 = f21 * u1 + f22 * v1 + f23, c2 = f31 * u1 + f32 * v1 + f33;
@@ -256,7 +260,54 @@ __global__ __launch_bounds__(64) void check_fundamental_kernel(const CheckFArgs 
     a.scores[hyp] = score;
 }
 
+// InitHelper::Normalize (reference src/initialization.cpp:365-410) for a batch of point sets, one workgroup per set.  The means
+// and the mean absolute deviations are sequential f32 sums in point order -- the one thing that cannot be parallelised without
+// changing the bits -- so two lanes (x and y) walk the points twice; the shift and scale of the points, which is the bulk of
+// the bytes, runs on all 256 lanes.  With a mask (the tracker's status bytes) lost points are skipped exactly as if they had
+// been erased from the vectors first (:621-635), which is what keeps LK's output on the device up to the inlier vote.
+__global__ __launch_bounds__(256) void normalize_points_kernel(const NormArgs a)
+{
+    __shared__ float sh[4];                         // meanX, meanY, sX, sY
+    const int t = threadIdx.x;
+    const float* __restrict__ xy = a.xy + (long long)blockIdx.x * a.xy_step;
+    const uint8_t* __restrict__ mask = a.mask ? a.mask + (long long)blockIdx.x * a.mask_step : nullptr;
+    float* __restrict__ out = a.out_xy + (long long)blockIdx.x * a.xy_step;
+    if (t < 2) {
+        float sum = 0.f;
+        int N = 0;
+        for (int i = 0; i < a.n; ++i)
+            if (!mask || mask[i]) { sum += xy[2 * i + t]; ++N; }
+        const float mean = sum / (float)N;
+        float dev = 0.f;
+        for (int i = 0; i < a.n; ++i)
+            if (!mask || mask[i]) dev += fabsf(xy[2 * i + t] - mean);
+        dev = dev / (float)N;
+        sh[t] = mean;
+        sh[2 + t] = (float)(1.0 / (double)dev);
+    }
+    __syncthreads();
+    const float meanX = sh[0], meanY = sh[1], sX = sh[2], sY = sh[3];
+    for (int i = t; i < a.n; i += 256) {
+        const bool ok = !mask || mask[i];
+        out[2 * i] = ok ? (xy[2 * i] - meanX) * sX : 0.f;
+        out[2 * i + 1] = ok ? (xy[2 * i + 1] - meanY) * sY : 0.f;
+    }
+    if (t == 0) {
+        float* T = a.T + 9 * (long long)blockIdx.x;
+        T[0] = sX; T[1] = 0.f; T[2] = -meanX * sX;
+        T[3] = 0.f; T[4] = sY; T[5] = -meanY * sY;
+        T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s)
+{
+    if (a.n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_points_kernel, dim3(a.n_sets), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s)
 {

@@ -231,6 +231,21 @@ int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int
  * scores: n_hyp f32 out; inliers: n_hyp x n u8 out or NULL.  Host buffers. */
 int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const float* pts1, const float* pts2,
                              int n, float sigma, float* scores, uint8_t* inliers);
+/* the same on device-resident data, enqueued on the context's stream (dr3hip_sync to wait): d_pts1 / d_pts2 are e.g.
+ * dr3hip_batch_track's prev_xy / next_xy of one pair and d_mask its status bytes (NULL = every match counts): a match with mask 0
+ * was lost by the tracker; the reference erases it from both vectors before the vote (src/initialization.cpp:621-635), here it is
+ * skipped in place, which leaves the sequential f32 score bit-identical; its inlier byte is 0. */
+int dr3hip_check_fundamental_dev(dr3hip_ctx* ctx, const float* d_F21, int n_hyp, const float* d_pts1, const float* d_pts2,
+                                 const uint8_t* d_mask, int n, float sigma, float* d_scores, uint8_t* d_inliers);
+/* InitHelper::Normalize (reference src/initialization.cpp:365-410, called twice from FindFundamental :84-85): the points shifted by
+ * their mean and scaled by the inverse mean absolute deviation, and T = [sX 0 -meanX*sX; 0 sY -meanY*sY; 0 0 1] (f32 row-major).
+ * Means and deviations are the reference's sequential f32 sums.  xy / out_xy: n (x, y) f32 pairs.  Host buffers. */
+int dr3hip_normalize_points(dr3hip_ctx* ctx, const float* xy, int n, float* out_xy, float T[9]);
+/* n_sets point sets of n points each (set k at d_xy + 2*n*k floats, its mask at d_mask + n*k bytes, its T at d_T + 9*k) in one
+ * launch, device-resident, enqueued on the context's stream.  d_mask as for dr3hip_check_fundamental_dev (NULL = all points);
+ * masked-out points come back as (0, 0). */
+int dr3hip_normalize_points_dev(dr3hip_ctx* ctx, const float* d_xy, const uint8_t* d_mask, int n, int n_sets,
+                                float* d_out_xy, float* d_T);
 
 /* ---- spherical / cylindrical pre-warp ------------------------------------------------- */
 /* utils::warp_spherical / warp_cylindrical (reference src/utils.cpp:196-201, :267-272): map generation

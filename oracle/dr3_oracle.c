@@ -657,6 +657,43 @@ float dr3o_check_fundamental(const float F21[9], const float* pts1, const float*
     return score;
 }
 
+/* InitHelper::Normalize (src/initialization.cpp:365-410): means and mean absolute deviations as SEQUENTIAL f32 sums in point
+ * order, sX = 1.0 / meanDevX (a double division rounded to float: the same bits as the f32 division), points shifted and scaled,
+ * T = [sX 0 -meanX*sX; 0 sY -meanY*sY; 0 0 1].  mask (may be NULL): points with mask[i] == 0 are skipped as if erased from the
+ * vector beforehand (the reference erases lost points at :621-635); their output is (0, 0). */
+void dr3o_normalize_points(const float* xy, const uint8_t* mask, int n, float* out_xy, float T[9])
+{
+    float meanX = 0, meanY = 0, meanDevX = 0, meanDevY = 0, sX, sY;
+    int i, N = 0;
+    for (i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        meanX += xy[2 * i];
+        meanY += xy[2 * i + 1];
+        ++N;
+    }
+    meanX = meanX / N;
+    meanY = meanY / N;
+    for (i = 0; i < n; ++i) {
+        if (mask && !mask[i]) { out_xy[2 * i] = 0.f; out_xy[2 * i + 1] = 0.f; continue; }
+        out_xy[2 * i] = xy[2 * i] - meanX;
+        out_xy[2 * i + 1] = xy[2 * i + 1] - meanY;
+        meanDevX += fabsf(out_xy[2 * i]);
+        meanDevY += fabsf(out_xy[2 * i + 1]);
+    }
+    meanDevX = meanDevX / N;
+    meanDevY = meanDevY / N;
+    sX = (float)(1.0 / meanDevX);
+    sY = (float)(1.0 / meanDevY);
+    for (i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        out_xy[2 * i] = out_xy[2 * i] * sX;
+        out_xy[2 * i + 1] = out_xy[2 * i + 1] * sY;
+    }
+    T[0] = sX; T[1] = 0.f; T[2] = -meanX * sX;
+    T[3] = 0.f; T[4] = sY; T[5] = -meanY * sY;
+    T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* A-4 / A-5  warpPerspective, remap                                                          */
 /* ------------------------------------------------------------------------------------------ */

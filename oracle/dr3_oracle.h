@@ -134,6 +134,8 @@ int  dr3o_fast_detect_grid(const uint8_t* const* levels, const int* strides, int
  * fundamental matrix F21 (row-major f32) over n matched points (pts1 = kp1.pt, pts2 = kp2.pt as x,y f32 pairs);
  * inliers (n bytes, may be NULL).  f32 arithmetic exactly as written, sequential score accumulation. */
 float dr3o_check_fundamental(const float F21[9], const float* pts1, const float* pts2, int n, float sigma, uint8_t* inliers);
+/* InitHelper::Normalize (src/initialization.cpp:365-410); mask may be NULL */
+void dr3o_normalize_points(const float* xy, const uint8_t* mask, int n, float* out_xy, float T[9]);
 
 /* reconstruct::Stitch::process, the part after align_pair (src/stitch.cpp:33-80).
  * geometry (:33-71): Hinv = H.inv() (cv::invert, CV_32F 3x3: closed form in double, stored as float), scaled by

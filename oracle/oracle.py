@@ -107,6 +107,8 @@ def lib():
         L.dr3o_fast_detect_grid.restype = ip
         L.dr3o_check_fundamental.argtypes = [vp, vp, vp, ip, C.c_float, vp]
         L.dr3o_check_fundamental.restype = C.c_float
+        L.dr3o_normalize_points.argtypes = [vp, vp, ip, vp, vp]
+        L.dr3o_normalize_points.restype = None
         L.dr3o_stitch_geometry.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
         L.dr3o_stitch_geometry.restype = ip
         L.dr3o_stitch_compose.argtypes = [vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip, vp, ip]
@@ -402,6 +404,16 @@ def check_fundamental(F21, pts1, pts2, sigma=1.0):
     inl = np.zeros(len(p1), np.uint8)
     sc = lib().dr3o_check_fundamental(_p(F), _p(p1), _p(p2), len(p1), C.c_float(sigma), _p(inl))
     return np.float32(sc), inl
+
+
+def normalize_points(xy, mask=None):
+    """InitHelper::Normalize (src/initialization.cpp:365-410) -> (normalised points (n,2) f32, T (3,3) f32)"""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros_like(xy); T = np.zeros(9, np.float32)
+    with np.errstate(all="ignore"):
+        lib().dr3o_normalize_points(_p(xy), None if m is None else _p(m), len(xy), _p(out), _p(T))
+    return out, T.reshape(3, 3)
 
 
 def stitch_geometry(H, w, h):

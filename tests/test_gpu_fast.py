@@ -98,6 +98,81 @@ def test_check_fundamental_all_hypotheses_bit_exact(dr3, O, ctx, synth):
     assert np.array_equal(sc, np.zeros(3, np.float32))
 
 
+def test_normalize_points_bit_exact(dr3, O, ctx):
+    """InitHelper::Normalize (src/initialization.cpp:365-410): normalised points and T equal the oracle's sequential f32
+    arithmetic bit for bit; on device-resident sets with a mask (the tracker's status bytes) a lost point is skipped exactly as
+    if it had been erased from the vector first (:621-635)"""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 9, 546, 5000):
+        xy = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n)], 1).astype(np.float32)
+        g_xy, g_T = ctx.normalize_points(xy)
+        o_xy, o_T = O.normalize_points(xy)
+        assert np.array_equal(g_xy.view(np.uint32), o_xy.view(np.uint32)) and np.array_equal(g_T.view(np.uint32), o_T.view(np.uint32)), n
+    n, n_sets = 2000, 5
+    sets = np.stack([np.stack([rng.uniform(-50, 1300, n), rng.uniform(-20, 400, n)], 1) for _ in range(n_sets)]).astype(np.float32)
+    mask = (rng.random((n_sets, n)) < 0.85).astype(np.uint8)
+    mask[3] = 1                                                              # one set without losses
+    d_xy, d_m = ctx.to_device(sets), ctx.to_device(mask)
+    d_out, d_T = ctx.alloc(sets.nbytes), ctx.alloc(n_sets * 36)
+    try:
+        ctx.normalize_points_dev(d_xy, d_m, n, n_sets, d_out, d_T); ctx.sync()
+        out = d_out.download((n_sets, n, 2), np.float32); T = d_T.download((n_sets, 3, 3), np.float32)
+        for k in range(n_sets):
+            keep = mask[k] == 1
+            o_xy, o_T = O.normalize_points(sets[k][keep])                    # the reference's way: erase, then normalise
+            assert np.array_equal(out[k][keep].view(np.uint32), o_xy.view(np.uint32)) and np.array_equal(T[k].view(np.uint32), o_T.view(np.uint32)), k
+            assert not out[k][~keep].any()
+            m_xy, m_T = O.normalize_points(sets[k], mask[k])                 # and the oracle's own mask form agrees with that
+            assert np.array_equal(m_xy.view(np.uint32), out[k].view(np.uint32)) and np.array_equal(m_T.view(np.uint32), o_T.view(np.uint32))
+        ctx.normalize_points_dev(d_xy, None, n, n_sets, d_out, d_T); ctx.sync()
+        out = d_out.download((n_sets, n, 2), np.float32)
+        assert np.array_equal(out[0].view(np.uint32), O.normalize_points(sets[0])[0].view(np.uint32))
+    finally:
+        for d in (d_xy, d_m, d_out, d_T):
+            d.free()
+
+
+def test_tracks_stay_on_the_device_up_to_the_inlier_vote(dr3, O, ctx, synth):
+    """LK -> Normalize -> CheckFundamental without the points leaving the GPU (SURVEY 8f.4's reason to exist): the tracker's
+    device outputs (prev_xy, next_xy, status) feed dr3hip_normalize_points_dev and dr3hip_check_fundamental_dev directly; both
+    equal the oracle run the reference's way (lost points erased from the vectors first)"""
+    A, B, Tm = synth.frame_pair(640, 400)
+    pts = synth.grid_points(640, 400, 20)
+    pts = np.vstack([pts, [[-30, 5], [700, 100], [3, 399]]]).astype(np.float32)          # some points the tracker will lose
+    n = len(pts)
+    b = dr3.FrameBatch(ctx, 640, 400, win=(15, 15), max_level=3, capacity=2)
+    d_prev, d_next = ctx.to_device(pts), ctx.to_device(pts)
+    d_st, d_err = ctx.alloc(n), ctx.alloc(4 * n)
+    n_hyp = 64
+    rng = np.random.default_rng(9)
+    Fs = rng.normal(0, 1e-4, (n_hyp, 3, 3)).astype(np.float32); Fs[:, 2, 2] = 1e-2
+    d_F, d_sc, d_in = ctx.to_device(Fs), ctx.alloc(4 * n_hyp), ctx.alloc(n_hyp * n)
+    d_n1, d_n2, d_T = ctx.alloc(8 * n), ctx.alloc(8 * n), ctx.alloc(72)
+    try:
+        b.upload(0, np.stack([A, B])); b.build(0, 2, True)
+        b.track(1, 0, d_prev, d_next, n, d_st, d_err, dr3.lk_params(win=(15, 15), max_level=3, max_iters=30, eps=0.01))
+        ctx.normalize_points_dev(d_prev, d_st, n, 1, d_n1, d_T)
+        ctx.normalize_points_dev(d_next, d_st, n, 1, d_n2, d_T.ptr + 36)
+        ctx.check_fundamental_dev(d_F, n_hyp, d_prev, d_next, d_st, n, 1.0, d_sc, d_in)
+        ctx.sync()
+        st = d_st.download((n,), np.uint8); nxt = d_next.download((n, 2), np.float32)
+        keep = st == 1
+        assert 0 < (~keep).sum() < n // 4
+        o1, T1 = O.normalize_points(pts[keep]); o2, T2 = O.normalize_points(nxt[keep])
+        T = d_T.download((2, 3, 3), np.float32)
+        assert np.array_equal(T[0].view(np.uint32), T1.view(np.uint32)) and np.array_equal(T[1].view(np.uint32), T2.view(np.uint32))
+        assert np.array_equal(d_n1.download((n, 2), np.float32)[keep].view(np.uint32), o1.view(np.uint32))
+        assert np.array_equal(d_n2.download((n, 2), np.float32)[keep].view(np.uint32), o2.view(np.uint32))
+        sc = d_sc.download((n_hyp,), np.float32); inl = d_in.download((n_hyp, n), np.uint8)
+        for h in range(n_hyp):
+            o_sc, o_in = O.check_fundamental(Fs[h], pts[keep], nxt[keep], 1.0)
+            assert sc[h].view(np.uint32) == o_sc.view(np.uint32) and np.array_equal(inl[h][keep], o_in) and not inl[h][~keep].any(), h
+    finally:
+        for d in (d_prev, d_next, d_st, d_err, d_F, d_sc, d_in, d_n1, d_n2, d_T):
+            d.free()
+        b.close()
+
+
 def test_batch_detect_matches_host_detect_and_feeds_the_tracker(dr3, O, ctx, synth):
     """device-resident front end (dr3hip_batch_detect): per slot the same cells as the host-image entry point and the
     oracle -- including the odd-width KITTI shape, where the reference's half-sampler walks the level-0 image as a

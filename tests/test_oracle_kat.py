@@ -264,3 +264,20 @@ def test_lk_non_finite_points_are_lost(O, synth):
         xy, st, err, _ = O.lk_track(A, B, pts, None, O.lk_params(win=(9, 9), max_level=2, max_iters=10, eps=0.01, flags=0), order=order)
         assert st.tolist() == [0, 0, 0, 0, 0, 0, 1] and not err[:6].any()
         assert np.array_equal(xy[:6], pts[:6], equal_nan=True)
+
+
+def test_normalize_points_known_answers(O):
+    """InitHelper::Normalize (src/initialization.cpp:365-410): a symmetric cross has mean 0 and mean |dev| = its arm lengths"""
+    xy = np.array([[3, 0], [-3, 0], [0, 5], [0, -5]], np.float32) + np.float32([100, 40])
+    out, T = O.normalize_points(xy)
+    # mean (100, 40); mean |dx| = 6/4 = 1.5, mean |dy| = 10/4 = 2.5
+    assert np.allclose(T, [[1 / 1.5, 0, -100 / 1.5], [0, 1 / 2.5, -40 / 2.5], [0, 0, 1]], rtol=1e-6)
+    assert np.allclose(out, [[2, 0], [-2, 0], [0, 2], [0, -2]], atol=1e-5)
+    assert np.allclose(np.abs(out).mean(0), 1.0, atol=1e-6)                     # the normalised points have unit mean deviation
+    # T maps the original points onto the normalised ones
+    h = (T @ np.c_[xy, np.ones(4)].T).T
+    assert np.allclose(h[:, :2], out, atol=1e-4)
+    # a masked point is skipped as if erased
+    xy5 = np.vstack([xy, [[1e6, -1e6]]]).astype(np.float32)
+    out5, T5 = O.normalize_points(xy5, np.array([1, 1, 1, 1, 0], np.uint8))
+    assert np.array_equal(T5, T) and np.array_equal(out5[:4], out) and not out5[4].any()
