@@ -1271,6 +1271,19 @@ static bool warp_fast_coords_ok(const double M[9], int sw, int sh, int dw, int d
     return bx < 4294967296.0 * wmin && by < 4294967296.0 * wmin;
 }
 
+// May the 4-pixel lanes derive pixels 1..3 from pixel 0 in f32 (warp_kernels.hip, persp_taps4_delta)?  On top of the conditions
+// above: q = M6 / W at most 1.2e-4 in magnitude and the source moves by at most 2 px per destination pixel along x, over the
+// whole destination (both are largest where |W| is smallest; source coordinates are bounded by 8000 px there already).
+static bool warp_delta_coords_ok(const double M[9], int dw, int dh)
+{
+    double wmin = INFINITY;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
+        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double q = std::fabs(M[6]) / wmin;
+    const double dxdx = (std::fabs(M[0]) / wmin) + q * 8000.0, dydx = (std::fabs(M[3]) / wmin) + q * 8000.0;
+    return q <= 1.2e-4 && dxdx <= 2.0 && dydx <= 2.0;
+}
+
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags)
 {
@@ -1286,7 +1299,7 @@ static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride
     j.bw0_shift = -1;
     if (j.bw0 >= dw) j.bw0_shift = 31;                                    // x0 == 0 for every x
     else if (j.bw0 >= 64 && (j.bw0 & (j.bw0 - 1)) == 0) j.bw0_shift = __builtin_ctz((unsigned)j.bw0);
-    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? 1 : 0;
+    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? (warp_delta_coords_ok(Md, dw, dh) ? 2 : 1) : 0;
 }
 
 int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs, int type, int flags)

@@ -70,7 +70,8 @@ struct WarpJobDev {
     double M[9];        // inverse map (dst -> src), already inverted on the host
     int bw0;            // WarpPerspectiveInvoker block width (x0/x1 split)
     int bw0_shift;      // log2(bw0) if bw0 is a power of two >= 64; 31 if one block spans the row; else -1 (generic kernel)
-    int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191)
+    int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191); 2: also its
+                        // one-reciprocal-per-four-pixels form (nearly affine map: warp_delta_coords_ok)
 };
 
 struct StitchArgs {        // fused Stitch compose (src/stitch.cpp:72-80): job[0] = left (M = T), job[1] = right (M = T * Hinv)

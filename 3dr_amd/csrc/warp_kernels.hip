@@ -92,11 +92,58 @@ __device__ __forceinline__ bool persp_tap_fast(const double* __restrict__ M, con
     return !near_tie;
 }
 
+// Four adjacent pixels from ONE reciprocal: X_k = (N_0 + k M0) r_0 / (1 + k q) with q = M6 r_0 exactly, so
+// X_k - X_0 = k c / (1 + k q), c = M0 r_0 - q X_0.  The lane evaluates pixel 0 as above (f64, fixed point with 13 extra bits) and
+// the three offsets k c (1 - k q) in f32.  Error budget in units of 2^-13 of 1/32 px, bounded by the host for jobs flagged
+// fast == 2 (warp_delta_coords_ok: |q| <= 1.2e-4, |dX/dx|, |dY/dx| <= 2): truncation of pixel 0 < 1, rounding of the offset 0.5,
+// its f32 evaluation < 0.3, the dropped (k q)^2 term < 0.25 -- under 2.05 in all, so a value at least 3 units away from a
+// rounding tie decides exactly like the f64 sequence; the others (1.5e-3 of the pixels) are recomputed by that sequence.
+template <bool GENERIC>
+__device__ __forceinline__ void persp_taps4_delta(const double* __restrict__ M, int bw0, int bw0_shift, int x, int y, Tap t[4])
+{
+    const double xd = (double)x, yd = (double)y;
+    const double W0 = __builtin_fma(M[6], xd, __builtin_fma(M[7], yd, M[8]));
+    const double NX = __builtin_fma(M[0], xd, __builtin_fma(M[1], yd, M[2]));
+    const double NY = __builtin_fma(M[3], xd, __builtin_fma(M[4], yd, M[5]));
+    double r = __builtin_amdgcn_rcp(W0);
+    r = __builtin_fma(__builtin_fma(-W0, r, 1.0), r, r);
+    const double rs = r * 262144.0;                       // 32 * 2^13
+    const double X0 = NX * rs, Y0 = NY * rs;
+    const double q = M[6] * r;
+    const float cx = (float)__builtin_fma(-q, X0, M[0] * rs), cy = (float)__builtin_fma(-q, Y0, M[3] * rs), qf = (float)q;
+    const float cx2 = cx * qf, cy2 = cy * qf;
+    const int aX0 = (int)X0 + 4096, aY0 = (int)Y0 + 4096;  // |.| < 2^31: host check
+    bool exact[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int aX = aX0, aY = aY0;
+        if (k) {
+            const float fk = (float)k;
+            aX += __float2int_rn((cx - fk * cx2) * fk);
+            aY += __float2int_rn((cy - fk * cy2) * fk);
+        }
+        t[k].sx = aX >> 18; t[k].fx = (aX >> 13) & 31;
+        t[k].sy = aY >> 18; t[k].fy = (aY >> 13) & 31;
+        exact[k] = (((uint32_t)(aX + 3) & 8191u) < 6u) | (((uint32_t)(aY + 3) & 8191u) < 6u);
+    }
+    if (exact[0] | exact[1] | exact[2] | exact[3]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (exact[k]) {
+                const int x0 = GENERIC ? block_origin(x + k, bw0, bw0_shift) : (((x + k) >> bw0_shift) << bw0_shift);
+                t[k] = persp_tap(M, persp_base(M, x0, y), (double)(x + k - x0));
+            }
+    }
+}
+
 // NPX adjacent destination pixels x..x+NPX-1 of row y.  They share the block origin whenever the
 // block width is a multiple of NPX (always, except for destinations shorter than 16 rows).
 template <int NPX, bool GENERIC>
-__device__ __forceinline__ void persp_taps(const double* __restrict__ M, int bw0, int bw0_shift, bool fast, int x, int y, Tap t[NPX])
+__device__ __forceinline__ void persp_taps(const double* __restrict__ M, int bw0, int bw0_shift, int fast, int x, int y, Tap t[NPX])
 {
+#ifndef DR3_WARP_NO_DELTA
+    if (NPX == 4 && fast == 2) { persp_taps4_delta<GENERIC>(M, bw0, bw0_shift, x, y, t); return; }
+#endif
     // !GENERIC: every job of the launch has a power-of-two block width >= 4 (or one block per row), so
     // the NPX pixels of a lane share the origin and no integer division is compiled in
     const int x0 = GENERIC ? block_origin(x, bw0, bw0_shift) : ((x >> bw0_shift) << bw0_shift);
@@ -381,7 +428,7 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const WarpJobDev*
         const int y = (blockIdx.y * 4 + threadIdx.y) * WT::LY + (threadIdx.x >> WT::LOG_LX);
         if (y >= dh) return;
         Tap t[P::PXT];
-        persp_taps<P::PXT, GENERIC>(M, bw0, bw0_shift, jb.fast != 0, x, y, t);
+        persp_taps<P::PXT, GENERIC>(M, bw0, bw0_shift, jb.fast, x, y, t);
         if (P::PXT == 4) quad_8u<TYPE>((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, (gu8)jb.dst, dw, jb.dstride, x, y, t);
         else             single_px<TYPE>((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, (gu8)jb.dst, jb.dstride, x, y, t[0]);
     }
@@ -470,7 +517,7 @@ __global__ __launch_bounds__(256) void stitch_compose_kernel(const StitchArgs a)
 #pragma unroll
         for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
         Tap t[4];
-        persp_taps<4, GENERIC>(M, jb.bw0, jb.bw0_shift, jb.fast != 0, x, y, t);
+        persp_taps<4, GENERIC>(M, jb.bw0, jb.bw0_shift, jb.fast, x, y, t);
         gcu8 src = (gcu8)jb.src;
         const bool src_aligned = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)jb.sstride) & 3) == 0 &&
                                  jb.sstride < (1 << 24) && jb.sh < (1 << 24) && (long long)jb.sstride * jb.sh < (1LL << 31);
@@ -520,7 +567,7 @@ __global__ __launch_bounds__(256) void panorama_add_kernel(const PanoAddArgs a)
 #pragma unroll
     for (int i = 0; i < 9; ++i) M[i] = a.M[i];
     Tap t[1];
-    persp_taps<1, GENERIC>(M, a.bw0, a.bw0_shift, a.fast != 0, x, y, t);
+    persp_taps<1, GENERIC>(M, a.bw0, a.bw0_shift, a.fast, x, y, t);
     const int sx = t[0].sx, sy = t[0].sy, sw = a.w, sh = a.h;
     if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return;      // every tap is border 0: scaled BGR == 0
     gcu8 src = (gcu8)a.img;
