@@ -32,7 +32,7 @@ WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 MAX_LEVELS, MAX_WIN = 8, 32
-PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH, PROF_ALIGN = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 COMM_ID_BYTES = 128
 WARP_SPHERICAL, WARP_CYLINDRICAL = 1, 2
 NO_POINT = np.float32(-1.0e6)
@@ -46,6 +46,11 @@ class LKParams(C.Structure):
     _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
                 ("crit_type", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
                 ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int), ("eps", C.c_double)]
 
 
 class LevelInfo(C.Structure):
@@ -111,6 +116,7 @@ def _signatures():
         "dr3hip_batch_download": ([vp, ip, ip, ip, vp, ip], ip),
         "dr3hip_batch_build": ([vp, ip, ip, ip], ip),
         "dr3hip_batch_track": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, P(LKParams)], ip),
+        "dr3hip_batch_align": ([vp, ip, ip, vp, vp, vp, ip, P(AlignParams), vp, vp, vp, vp], ip),
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
@@ -176,6 +182,11 @@ def lk_params(win=(21, 21), max_level=3, max_iters=30, eps=0.01, crit_type=CRIT_
               flags=0, min_eig_threshold=1e-4):
     return LKParams(int(win[0]), int(win[1]), int(max_level), int(crit_type), int(max_iters),
                     float(eps), int(flags), float(min_eig_threshold))
+
+
+def align_params(fx, fy, cx, cy, max_level=4, min_level=2, n_iter=10, eps=1e-8):
+    """parameters of dr3hip_batch_align (sparse image alignment, an extension specified by this build)"""
+    return AlignParams(float(fx), float(fy), float(cx), float(cy), int(max_level), int(min_level), int(n_iter), float(eps))
 
 
 def lk_params_reference():
@@ -540,6 +551,13 @@ class FrameBatch:
         out = np.empty((li.h, li.w, 2), np.int16)
         self.ctx._chk(lib().dr3hip_batch_download(self.h, slot, level, 1, _p(out), out.strides[0]))
         return out
+
+    def align(self, n_pairs, first_slot, d_xyz, n_pts, params, d_T, d_n_meas=None, d_chi2=None, d_iters=None,
+              d_ref_slot=None, d_cur_slot=None):
+        """sparse image alignment of n_pairs frame pairs (dr3hip_batch_align); all d_* device buffers; enqueued"""
+        ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        self.ctx._chk(lib().dr3hip_batch_align(self.h, int(n_pairs), int(first_slot), ptr(d_ref_slot), ptr(d_cur_slot), ptr(d_xyz),
+                                               int(n_pts), C.byref(params), ptr(d_T), ptr(d_n_meas), ptr(d_chi2), ptr(d_iters)))
 
     def track(self, n_pairs, first_slot, d_prev_xy, d_next_xy, n_pts, d_status, d_err, params,
               d_prev_slot=None, d_next_slot=None, d_iters=None):

@@ -26,7 +26,7 @@ struct dr3hip_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // grow-only staging buffers for the host-buffer calls
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf stage[8];          // [7] is the bounce buffer of copy2d_h2d / copy2d_d2h
+    Buf stage[9];          // [7] is the bounce buffer of copy2d_h2d / copy2d_d2h, [8] the sparse alignment's patch cache
     dr3hip_batch* lk_batch = nullptr;     // cached 2-slot batch behind dr3hip_lk_track
     bool prof = false;
     double prof_ms[DR3HIP_PROF_SLOTS] = {0};
@@ -1123,6 +1123,37 @@ int dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
     }
     prof_end(ctx, pe);
     return L;
+}
+
+// ---- sparse image alignment (extension) -----------------------------------------------------------------
+int dr3hip_batch_align(dr3hip_batch* b, int n_pairs, int first_slot, const int* d_ref_slot, const int* d_cur_slot,
+                       const float* d_xyz, int n_pts, const dr3hip_align_params* p, double* d_T,
+                       int* d_n_meas, float* d_chi2, int* d_iters)
+{
+    if (!b) return DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    if (!p || !d_xyz || !d_T || n_pairs < 0 || n_pts < 0 || n_pts > (1 << 22)) return fail(ctx, DR3HIP_EINVAL, "batch_align: bad arguments");
+    if (!d_ref_slot != !d_cur_slot) return fail(ctx, DR3HIP_EINVAL, "batch_align: give both slot arrays or neither");
+    if (!d_ref_slot && (first_slot < 0 || first_slot + n_pairs + 1 > b->capacity))
+        return fail(ctx, DR3HIP_EINVAL, "batch_align: pairs [%d,%d] outside capacity %d", first_slot, first_slot + n_pairs, b->capacity);
+    if (p->min_level < 0 || p->max_level < p->min_level || p->max_level >= b->levels || p->n_iter < 0)
+        return fail(ctx, DR3HIP_EINVAL, "batch_align: levels %d..%d not in the batch's pyramid (%d levels) or n_iter < 0", p->min_level, p->max_level, b->levels);
+    if (n_pairs == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    const size_t per_pair = (size_t)((n_pts + 255) / 256) * 16 * 7 * 256 * sizeof(float);
+    int rc;
+    if ((rc = stage_reserve(ctx, 8, per_pair * (size_t)n_pairs + 256))) return rc;
+    AlignArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < b->levels; ++l) a.lv[l] = b->lv[l];
+    a.fx = p->fx; a.fy = p->fy; a.cx = p->cx; a.cy = p->cy;
+    a.max_level = p->max_level; a.min_level = p->min_level; a.n_iter = p->n_iter; a.eps = p->eps;
+    a.n_pts = n_pts; a.first_slot = first_slot; a.ref_slot = d_ref_slot; a.cur_slot = d_cur_slot;
+    a.xyz = d_xyz; a.cache = (float*)ctx->stage[8].p; a.T = d_T; a.n_meas = d_n_meas; a.chi2 = d_chi2; a.iters = d_iters;
+    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_ALIGN, pe);
+    HIPCHK(ctx, launch_sparse_align(a, n_pairs, ctx->stream));
+    prof_end(ctx, pe);
+    return DR3HIP_OK;
 }
 
 // ---- host-buffer LK -------------------------------------------------------------------------------

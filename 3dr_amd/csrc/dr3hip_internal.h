@@ -109,6 +109,19 @@ struct FastArgs {          // FAST-10 score map + grid-best selection of one pyr
     int n_cells;                                  // cells (and occupancy bytes) per frame
 };
 
+struct AlignArgs {         // sparse_align_kernel (align_kernels.hip): one workgroup per frame pair
+    LevelDev lv[DR3HIP_MAX_LEVELS];
+    float fx, fy, cx, cy;
+    int max_level, min_level, n_iter;
+    double eps;
+    int n_pts, first_slot;
+    const int* ref_slot; const int* cur_slot;     // optional slot indirection, as dr3hip_batch_track
+    const float* xyz;                             // n_pairs x n_pts x 3, reference camera frame, Z <= 0 = no point
+    float* cache;                                 // workspace: n_pairs x ceil(n_pts / 256) x 16 x 7 x 256 floats
+    double* T;                                    // n_pairs x 12, in/out
+    int* n_meas; float* chi2; int* iters;         // n_pairs (iters: n_pairs x DR3HIP_MAX_LEVELS), each may be null
+};
+
 struct NormArgs {          // InitHelper::Normalize for n_sets point sets (fast_kernels.hip)
     const float* xy; long long xy_step;           // set k: n points (x, y) at xy + k * xy_step floats
     const uint8_t* mask; long long mask_step;     // optional: 0 = the point was erased (lost by the tracker); bytes between sets
@@ -164,6 +177,7 @@ hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
 hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s);
+hipError_t launch_sparse_align(const AlignArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);

@@ -47,8 +47,9 @@ class Texture:
         ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
         if T is not None:
             Ti = np.linalg.inv(np.asarray(T, np.float64))
-            X = Ti[0, 0] * xs + Ti[0, 1] * ys + Ti[0, 2]
-            Y = Ti[1, 0] * xs + Ti[1, 1] * ys + Ti[1, 2]
+            Wd = Ti[2, 0] * xs + Ti[2, 1] * ys + Ti[2, 2]          # 1 for the similarities; a plane-induced homography divides
+            X = (Ti[0, 0] * xs + Ti[0, 1] * ys + Ti[0, 2]) / Wd
+            Y = (Ti[1, 0] * xs + Ti[1, 1] * ys + Ti[1, 2]) / Wd
         else:
             X, Y = xs, ys
         out = [np.clip(np.rint(self._eval(c, X, Y)), 0, 255).astype(np.uint8) for c in range(self.channels)]
@@ -126,3 +127,32 @@ def tile_homography(i, w, h, seed=SEED):
     P = np.array([[1, 0, 0], [0, 1, 0], [rng.uniform(-1e-5, 1e-5), rng.uniform(-1e-5, 1e-5), 1.0]])
     Tr = np.array([[1, 0, rng.uniform(20, 120)], [0, 1, rng.uniform(20, 120)], [0, 0, 1.0]])
     return (Tr @ R @ P).astype(np.float32)
+
+
+# ---- sparse image alignment: a textured plane seen from two camera poses ---------------------------------
+def rodrigues(w):
+    """rotation matrix of the rotation vector w (f64)"""
+    w = np.asarray(w, np.float64)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def plane_scene(w, h, K, R, t, n=(0.05, -0.1, 1.0), d=12.0, seed=SEED):
+    """Two views of a textured plane n . X = d (reference camera frame): returns (ref image, cur image, H) where the current
+    camera sees X_cur = R X_ref + t.  A plane induces the homography H = K (R + t n^T / d) K^-1 between the views, so the second
+    image is the first one warped by H -- rendered analytically from the texture, no resampling of pixels."""
+    n = np.asarray(n, np.float64)
+    H = K @ (R + np.outer(t, n) / d) @ np.linalg.inv(K)
+    tex = Texture(w, h, seed)
+    return tex.render(), tex.render(H / H[2, 2]), H
+
+
+def plane_points(uv, K, n=(0.05, -0.1, 1.0), d=12.0):
+    """3-D points (reference camera frame, f32) of the pixels uv on the plane n . X = d"""
+    n = np.asarray(n, np.float64)
+    rays = (np.linalg.inv(K) @ np.c_[uv, np.ones(len(uv))].T).T
+    depth = d / (rays @ n)
+    return (rays * depth[:, None]).astype(np.float32)

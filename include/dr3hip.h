@@ -247,6 +247,27 @@ int dr3hip_normalize_points(dr3hip_ctx* ctx, const float* xy, int n, float* out_
 int dr3hip_normalize_points_dev(dr3hip_ctx* ctx, const float* d_xy, const uint8_t* d_mask, int n, int n_sets,
                                 float* d_out_xy, float* d_T);
 
+/* ---- 6-DoF inverse-compositional sparse image alignment ----------------------------------------------------
+ * EXTENSION SPECIFIED BY THIS BUILD: the reference only names this step (timer "sparse_img_align", src/handler.cpp:23; empty
+ * HandlerMono::process_frame, :80-82), so no reference parity exists; the algorithm (after Forster, Pizzoli, Scaramuzza, "SVO",
+ * ICRA 2014, IV-A) is specified in DESIGN.md section 4.8 and restated on the CPU by the test infrastructure, which the kernel equals
+ * bit for bit.  For every frame pair: features with known 3-D position in the reference camera frame (xyz, Z <= 0 = no point) and 4x4
+ * patches; Gauss-Newton over se(3) from level max_level down to min_level of the batch's pyramid, Jacobians taken once per level
+ * at the reference patch; T (12 doubles per pair, rows of [R | t], X_cur = R X_ref + t) is the initial guess and the result. */
+typedef struct dr3hip_align_params {
+    float fx, fy, cx, cy;      /* level-0 intrinsics (tests/test_pipeline.cpp:62-64) */
+    int   max_level, min_level;/* coarsest / finest level used; both must exist in the batch */
+    int   n_iter;              /* Gauss-Newton iterations per level (SVO: 10) */
+    double eps;                /* stop when the largest component of the update is below eps */
+} dr3hip_align_params;
+/* All d_* are device pointers; enqueued on the context's stream (dr3hip_sync to wait).  Pair i aligns slot
+ * d_cur_slot[i] (or first_slot + i + 1) to slot d_ref_slot[i] (or first_slot + i); d_xyz: n_pairs x n_pts x 3 f32;
+ * d_T: n_pairs x 12 f64 in/out; d_n_meas / d_chi2 (n_pairs: patch pixels used and mean squared residual of the last evaluation)
+ * and d_iters (n_pairs x DR3HIP_MAX_LEVELS, indexed by level) may be NULL. */
+int dr3hip_batch_align(dr3hip_batch* b, int n_pairs, int first_slot, const int* d_ref_slot, const int* d_cur_slot,
+                       const float* d_xyz, int n_pts, const dr3hip_align_params* p, double* d_T,
+                       int* d_n_meas, float* d_chi2, int* d_iters);
+
 /* ---- spherical / cylindrical pre-warp ------------------------------------------------- */
 /* utils::warp_spherical / warp_cylindrical (reference src/utils.cpp:196-201, :267-272): map generation
  * (compute_spherical_warping :125-187, compute_cylindrical_warping :203-265) fused with warp_local's
@@ -341,7 +362,8 @@ int dr3hip_timer_stop(dr3hip_ctx* ctx, float* ms);           /* synchronises on 
 #define DR3HIP_PROF_PANO_NORM 7
 #define DR3HIP_PROF_FAST      8 /* FAST score + select kernels of one dr3hip_fast_detect (all levels)   */
 #define DR3HIP_PROF_STITCH    9 /* fused stitch compose kernel                                        */
-#define DR3HIP_PROF_SLOTS   10
+#define DR3HIP_PROF_ALIGN    10 /* sparse image alignment kernel                                     */
+#define DR3HIP_PROF_SLOTS   11
 int dr3hip_profile_enable(dr3hip_ctx* ctx, int on);
 int dr3hip_profile_read(dr3hip_ctx* ctx, int which, double* total_ms, int* n_launch_groups);
 int dr3hip_profile_reset(dr3hip_ctx* ctx);

@@ -1083,3 +1083,205 @@ int dr3o_stitch_compose(const uint8_t* left, int lw, int lh, int lstride, const 
         }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* inverse-compositional sparse image alignment -- EXTENSION, see dr3_oracle.h */
+/* ------------------------------------------------------------------------------------------ */
+#define AL_LANES 256
+#define AL_NSUM 28            /* 21 entries of the upper triangle of H (row-major), 6 of g = sum J r, chi2 */
+#define AL_BORDER 3           /* patch half size 2 + 1 */
+
+typedef struct { float Iref[16]; float J[16][6]; int vis; } al_cache;
+
+static inline float al_bilin(const uint8_t* p, int stride, float wTL, float wTR, float wBL, float wBR)
+{
+    return ((wTL * (float)p[0] + wTR * (float)p[1]) + wBL * (float)p[stride]) + wBR * (float)p[stride + 1];
+}
+
+/* pixel position of a camera-frame point on level `scale`; 0 if the 4x4 patch (+1 px for its gradients) is not inside */
+static inline int al_project(float X, float Y, float Z, float fx, float fy, float cx, float cy, float scale, int w, int h,
+                             int* ui, int* vi, float wt[4], float* xn, float* yn)
+{
+    float x, y, u, v, fu, fv, sx, sy;
+    if (!(Z > 1e-6f)) return 0;
+    x = X / Z; y = Y / Z;
+    u = (fx * x + cx) * scale; v = (fy * y + cy) * scale;
+    if (!(fabsf(u) < 1.0e6f) || !(fabsf(v) < 1.0e6f)) return 0;
+    fu = floorf(u); fv = floorf(v);
+    *ui = (int)fu; *vi = (int)fv;
+    if (*ui - AL_BORDER < 0 || *vi - AL_BORDER < 0 || *ui + AL_BORDER >= w || *vi + AL_BORDER >= h) return 0;
+    sx = u - fu; sy = v - fv;
+    wt[0] = (1.f - sx) * (1.f - sy); wt[1] = sx * (1.f - sy); wt[2] = (1.f - sx) * sy; wt[3] = sx * sy;
+    *xn = x; *yn = y;
+    return 1;
+}
+
+/* the tracker's wave tree over 64 lane values (lk_kernels.hip wave_sum): upper half-wave onto the lower, upper 16 onto the lower
+ * 16, xor butterfly 1, 2, 4, 8 */
+static float al_wave_tree(const float* p)
+{
+    float a[32], c[16], b[16];
+    int l, off;
+    for (l = 0; l < 32; ++l) a[l] = p[l] + p[l + 32];
+    for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
+    for (off = 1; off < 16; off <<= 1) {
+        for (l = 0; l < 16; ++l) b[l] = c[l] + c[l ^ off];
+        memcpy(c, b, sizeof(c));
+    }
+    return c[0];
+}
+
+/* T <- T * exp(-x), x = (translation part, rotation part); 6-term series in theta^2 (exact rational coefficients) */
+static void al_update(double T[12], const double x[6])
+{
+    const double u0 = -x[0], u1 = -x[1], u2 = -x[2], w0 = -x[3], w1 = -x[4], w2 = -x[5];
+    const double th2 = (w0 * w0 + w1 * w1) + w2 * w2;
+    const double A = 1.0 - th2 * (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0)))));
+    const double B = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0) * (1.0 - th2 * (1.0 / 90.0) * (1.0 - th2 * (1.0 / 132.0))))));
+    const double C = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0) * (1.0 - th2 * (1.0 / 110.0) * (1.0 - th2 * (1.0 / 156.0))))));
+    /* W = [w]x, W2 = w w^T - th2 I */
+    const double W[9] = {0.0, -w2, w1, w2, 0.0, -w0, -w1, w0, 0.0};
+    const double W2[9] = {w0 * w0 - th2, w0 * w1, w0 * w2, w1 * w0, w1 * w1 - th2, w1 * w2, w2 * w0, w2 * w1, w2 * w2 - th2};
+    double Re[9], V[9], te[3], Rn[9], tn[3];
+    int i, j;
+    for (i = 0; i < 9; ++i) {
+        const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+        Re[i] = (id + A * W[i]) + B * W2[i];
+        V[i] = (id + B * W[i]) + C * W2[i];
+    }
+    for (i = 0; i < 3; ++i) te[i] = (V[3 * i] * u0 + V[3 * i + 1] * u1) + V[3 * i + 2] * u2;
+    for (i = 0; i < 3; ++i) {
+        for (j = 0; j < 3; ++j) Rn[3 * i + j] = (T[4 * i] * Re[j] + T[4 * i + 1] * Re[3 + j]) + T[4 * i + 2] * Re[6 + j];
+        tn[i] = ((T[4 * i] * te[0] + T[4 * i + 1] * te[1]) + T[4 * i + 2] * te[2]) + T[4 * i + 3];
+    }
+    for (i = 0; i < 3; ++i) { T[4 * i] = Rn[3 * i]; T[4 * i + 1] = Rn[3 * i + 1]; T[4 * i + 2] = Rn[3 * i + 2]; T[4 * i + 3] = tn[i]; }
+}
+
+/* H x = b, H symmetric 6x6 given by its upper triangle (row-major, 21 values), LDL^T without pivoting; 0 = not positive definite */
+static int al_solve(const float* Hf, const float* g, double x[6])
+{
+    double H[6][6], L[6][6], D[6], z[6];
+    int i, j, k, idx = 0;
+    for (i = 0; i < 6; ++i) for (j = i; j < 6; ++j) { H[i][j] = (double)Hf[idx]; H[j][i] = H[i][j]; ++idx; }
+    for (j = 0; j < 6; ++j) {
+        double d = H[j][j];
+        for (k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
+        if (!(d > 0.0)) return 0;
+        D[j] = d;
+        for (i = j + 1; i < 6; ++i) {
+            double s = H[i][j];
+            for (k = 0; k < j; ++k) s -= (L[i][k] * L[j][k]) * D[k];
+            L[i][j] = s / d;
+        }
+    }
+    for (i = 0; i < 6; ++i) { double s = -(double)g[i]; for (k = 0; k < i; ++k) s -= L[i][k] * z[k]; z[i] = s; }
+    for (i = 0; i < 6; ++i) z[i] = z[i] / D[i];
+    for (i = 5; i >= 0; --i) { double s = z[i]; for (k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s; }
+    for (i = 0; i < 6; ++i) if (!(fabs(x[i]) < 1.0e300)) return 0;
+    return 1;
+}
+
+int dr3o_sparse_align(const uint8_t* const* ref_levels, const uint8_t* const* cur_levels, const int* w, const int* h, const int* stride,
+                      int n_levels, const float* xyz, int n, const dr3o_align_params* p, double T[12],
+                      int* n_meas, float* chi2_out, int* iters)
+{
+    al_cache* cache;
+    int level, done = 0;
+    if (!ref_levels || !cur_levels || !w || !h || !stride || !xyz || !p || !T || n < 0) return -1;
+    if (p->max_level < p->min_level || p->min_level < 0 || p->max_level >= n_levels || p->n_iter < 0) return -2;
+    cache = (al_cache*)malloc(sizeof(al_cache) * (size_t)(n > 0 ? n : 1));
+    if (!cache) return -3;
+    if (n_meas) *n_meas = 0;
+    if (chi2_out) *chi2_out = 0.f;
+    for (level = p->max_level; level >= p->min_level; --level) {
+        const uint8_t* ref = ref_levels[level];
+        const uint8_t* cur = cur_levels[level];
+        const int lw = w[level], lh = h[level], ls = stride[level];
+        const float scale = 1.0f / (float)(1 << level);
+        const float fxl = p->fx * scale, fyl = p->fy * scale;
+        float chi2_prev = 0.f;
+        double T_old[12];
+        int f, it;
+        if (iters) iters[level] = 0;
+        /* ---- reference patches and their Jacobians, once per level ---------------------------------------- */
+        for (f = 0; f < n; ++f) {
+            al_cache* c = &cache[f];
+            const float X = xyz[3 * f], Y = xyz[3 * f + 1], Z = xyz[3 * f + 2];
+            int ui, vi, r, cc, py, px, k;
+            float wt[4], x, y, S[6][6], zi, j0[6], j1[6];
+            c->vis = al_project(X, Y, Z, p->fx, p->fy, p->cx, p->cy, scale, lw, lh, &ui, &vi, wt, &x, &y);
+            if (!c->vis) continue;
+            for (r = 0; r < 6; ++r)
+                for (cc = 0; cc < 6; ++cc)
+                    S[r][cc] = al_bilin(ref + (size_t)(vi + r - 3) * ls + (ui + cc - 3), ls, wt[0], wt[1], wt[2], wt[3]);
+            zi = 1.0f / Z;
+            j0[0] = -zi; j0[1] = 0.f; j0[2] = x * zi; j0[3] = x * y; j0[4] = -(1.0f + x * x); j0[5] = y;
+            j1[0] = 0.f; j1[1] = -zi; j1[2] = y * zi; j1[3] = 1.0f + y * y; j1[4] = -(x * y); j1[5] = -x;
+            for (py = 0; py < 4; ++py)
+                for (px = 0; px < 4; ++px) {
+                    const float dx = 0.5f * (S[py + 1][px + 2] - S[py + 1][px]);
+                    const float dy = 0.5f * (S[py + 2][px + 1] - S[py][px + 1]);
+                    const float gx = dx * fxl, gy = dy * fyl;
+                    c->Iref[4 * py + px] = S[py + 1][px + 1];
+                    for (k = 0; k < 6; ++k) c->J[4 * py + px][k] = gx * j0[k] + gy * j1[k];
+                }
+        }
+        /* ---- Gauss-Newton ------------------------------------------------------------------------------------ */
+        for (it = 0; it < p->n_iter; ++it) {
+            float part[AL_LANES][AL_NSUM];
+            int cnt[AL_LANES];
+            float tot[AL_NSUM], R32[9], t32[3], chi2m;
+            double x[6], mx;
+            int lane, wv, s, ntot = 0, i;
+            memset(part, 0, sizeof(part)); memset(cnt, 0, sizeof(cnt));
+            for (i = 0; i < 3; ++i) { R32[3 * i] = (float)T[4 * i]; R32[3 * i + 1] = (float)T[4 * i + 1]; R32[3 * i + 2] = (float)T[4 * i + 2]; t32[i] = (float)T[4 * i + 3]; }
+            for (lane = 0; lane < AL_LANES; ++lane) {
+                float* acc = part[lane];
+                for (f = lane; f < n; f += AL_LANES) {
+                    const al_cache* c = &cache[f];
+                    const float X = xyz[3 * f], Y = xyz[3 * f + 1], Z = xyz[3 * f + 2];
+                    float Xc, Yc, Zc, wt[4], xn, yn;
+                    int ui, vi, py, px, a, b;
+                    if (!c->vis) continue;
+                    Xc = ((R32[0] * X + R32[1] * Y) + R32[2] * Z) + t32[0];
+                    Yc = ((R32[3] * X + R32[4] * Y) + R32[5] * Z) + t32[1];
+                    Zc = ((R32[6] * X + R32[7] * Y) + R32[8] * Z) + t32[2];
+                    if (!al_project(Xc, Yc, Zc, p->fx, p->fy, p->cx, p->cy, scale, lw, lh, &ui, &vi, wt, &xn, &yn)) continue;
+                    for (py = 0; py < 4; ++py)
+                        for (px = 0; px < 4; ++px) {
+                            const float Ic = al_bilin(cur + (size_t)(vi + py - 2) * ls + (ui + px - 2), ls, wt[0], wt[1], wt[2], wt[3]);
+                            const float r = Ic - c->Iref[4 * py + px];
+                            const float* J = c->J[4 * py + px];
+                            int idx = 0;
+                            for (a = 0; a < 6; ++a) for (b = a; b < 6; ++b) { acc[idx] += J[a] * J[b]; ++idx; }
+                            for (a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+                            acc[27] += r * r;
+                            ++cnt[lane];
+                        }
+                }
+            }
+            for (s = 0; s < AL_NSUM; ++s) {
+                float wsum[4], lanes[64];
+                for (wv = 0; wv < 4; ++wv) { for (lane = 0; lane < 64; ++lane) lanes[lane] = part[64 * wv + lane][s]; wsum[wv] = al_wave_tree(lanes); }
+                tot[s] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+            }
+            for (lane = 0; lane < AL_LANES; ++lane) ntot += cnt[lane];
+            if (n_meas) *n_meas = ntot;
+            if (ntot == 0) break;
+            chi2m = tot[27] / (float)ntot;
+            if (chi2_out) *chi2_out = chi2m;
+            if (it > 0 && chi2m > chi2_prev) { memcpy(T, T_old, sizeof(T_old)); break; }
+            if (!al_solve(tot, tot + 21, x)) break;
+            memcpy(T_old, T, sizeof(T_old));
+            al_update(T, x);
+            chi2_prev = chi2m;
+            if (iters) iters[level] = it + 1;
+            mx = 0.0;
+            for (i = 0; i < 6; ++i) if (fabs(x[i]) > mx) mx = fabs(x[i]);
+            if (mx < p->eps) break;
+        }
+        ++done;
+    }
+    free(cache);
+    return done;
+}

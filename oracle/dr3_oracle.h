@@ -175,6 +175,28 @@ int  dr3o_feather_ramp(int min_x, int max_x, int feathering_width, float* ramp);
 int  dr3o_panorama_add(const uint8_t* img, int w, int h, int istride, float* canvas, int cw, int ch, int cstride,
                        const float M[9], int feathering_width, float* scratch, int n_threads);
 
+/* ---- 6-DoF inverse-compositional sparse image alignment -----------------------------------------------
+ * EXTENSION SPECIFIED BY THIS BUILD -- the reference only names it (timers "sparse_img_align" at src/handler.cpp:23, empty
+ * process_frame at :80-82, README.md TODO): NO REFERENCE PARITY IS POSSIBLE, this function IS the specification.  It follows the
+ * published algorithm (Forster, Pizzoli, Scaramuzza, "SVO", ICRA 2014, section IV-A; SVO's SparseImgAlign): features with known
+ * 3-D position in the reference camera frame, 4x4 patches, Gauss-Newton over se(3) per pyramid level coarse -> fine, Jacobians
+ * taken once per level at the reference patch.  Details fixed here so that the GPU kernel can be compared bit for bit:
+ * f32 per-pixel arithmetic without contraction, the summation order of the kernel (256 lanes x 4 waves, lane owns features
+ * lane, lane + 256, ...; lane partial sums in feature / pixel order, then the tracker's wave tree, then waves 0..3), the 6x6
+ * system solved in f64 by LDL^T without pivoting, the se(3) exponential by fixed 6-term series in theta^2. */
+typedef struct {
+    float fx, fy, cx, cy;          /* level-0 intrinsics (reference tests/test_pipeline.cpp:62-64) */
+    int   max_level, min_level;    /* coarsest and finest pyramid level used (SVO: 4 and 2) */
+    int   n_iter;                  /* Gauss-Newton iterations per level (SVO: 10) */
+    double eps;                    /* stop when max |update| < eps */
+} dr3o_align_params;
+/* levels: n_levels u8 images of one pyramid (level l: w[l] x h[l], stride[l]); xyz: n x 3 f32, Z <= 0 = no point.
+ * T (in/out): 12 doubles, [R | t] rows: cur = R * ref + t.  Returns the number of levels processed, < 0 on bad arguments.
+ * n_meas / chi2: measurements and mean squared residual of the last evaluation; iters: per level (index = level). */
+int dr3o_sparse_align(const uint8_t* const* ref_levels, const uint8_t* const* cur_levels, const int* w, const int* h, const int* stride,
+                      int n_levels, const float* xyz, int n, const dr3o_align_params* p, double T[12],
+                      int* n_meas, float* chi2, int* iters);
+
 #ifdef __cplusplus
 }
 #endif

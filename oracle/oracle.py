@@ -22,6 +22,11 @@ HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 CRIT_COUNT, CRIT_EPS = 1, 2
 
 
+class AlignParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("max_level", C.c_int), ("min_level", C.c_int), ("n_iter", C.c_int), ("eps", C.c_double)]
+
+
 class LKParams(C.Structure):
     _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
                 ("crit_type", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
@@ -109,6 +114,8 @@ def lib():
         L.dr3o_check_fundamental.restype = C.c_float
         L.dr3o_normalize_points.argtypes = [vp, vp, ip, vp, vp]
         L.dr3o_normalize_points.restype = None
+        L.dr3o_sparse_align.argtypes = [vp, vp, vp, vp, vp, ip, vp, ip, C.POINTER(AlignParams), vp, vp, vp, vp]
+        L.dr3o_sparse_align.restype = ip
         L.dr3o_stitch_geometry.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
         L.dr3o_stitch_geometry.restype = ip
         L.dr3o_stitch_compose.argtypes = [vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip, vp, ip]
@@ -414,6 +421,37 @@ def normalize_points(xy, mask=None):
     with np.errstate(all="ignore"):
         lib().dr3o_normalize_points(_p(xy), None if m is None else _p(m), len(xy), _p(out), _p(T))
     return out, T.reshape(3, 3)
+
+
+def align_params(fx, fy, cx, cy, max_level=4, min_level=2, n_iter=10, eps=1e-8):
+    return AlignParams(float(fx), float(fy), float(cx), float(cy), int(max_level), int(min_level), int(n_iter), float(eps))
+
+
+def lk_pyramid(img, n_levels):
+    """the Gaussian (pyrDown) pyramid the frame batch holds: level 0 .. n_levels - 1"""
+    pyr = [_gray(img)]
+    for _ in range(1, n_levels):
+        pyr.append(pyr_down(pyr[-1]))
+    return pyr
+
+
+def sparse_align(ref_pyr, cur_pyr, xyz, params, T0=None):
+    """6-DoF inverse-compositional sparse image alignment (EXTENSION specified by this build, dr3_oracle.h).
+    ref_pyr / cur_pyr: lists of u8 levels; xyz (n,3) f32 in the reference camera frame.
+    Returns (T (3,4) f64 [R|t], n_meas, chi2, iters per level)."""
+    n_levels = len(ref_pyr)
+    ref = [np.ascontiguousarray(a, np.uint8) for a in ref_pyr]; cur = [np.ascontiguousarray(a, np.uint8) for a in cur_pyr]
+    rp = (C.c_void_p * n_levels)(*[a.ctypes.data for a in ref]); cp = (C.c_void_p * n_levels)(*[a.ctypes.data for a in cur])
+    w = (C.c_int * n_levels)(*[a.shape[1] for a in ref]); h = (C.c_int * n_levels)(*[a.shape[0] for a in ref])
+    st = (C.c_int * n_levels)(*[a.strides[0] for a in ref])
+    assert all(a.shape == b.shape and a.strides == b.strides for a, b in zip(ref, cur))
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    T = np.ascontiguousarray(np.eye(3, 4) if T0 is None else T0, np.float64).copy()
+    n_meas = C.c_int(); chi2 = C.c_float(); iters = np.zeros(n_levels, np.int32)
+    r = lib().dr3o_sparse_align(rp, cp, w, h, st, n_levels, _p(xyz), len(xyz), C.byref(params), _p(T), C.byref(n_meas), C.byref(chi2), _p(iters))
+    if r < 0:
+        raise ValueError("dr3o_sparse_align failed: %d" % r)
+    return T, n_meas.value, np.float32(chi2.value), iters
 
 
 def stitch_geometry(H, w, h):

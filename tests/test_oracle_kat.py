@@ -281,3 +281,25 @@ def test_normalize_points_known_answers(O):
     xy5 = np.vstack([xy, [[1e6, -1e6]]]).astype(np.float32)
     out5, T5 = O.normalize_points(xy5, np.array([1, 1, 1, 1, 0], np.uint8))
     assert np.array_equal(T5, T) and np.array_equal(out5[:4], out) and not out5[4].any()
+
+
+def test_sparse_alignment_recovers_a_known_camera_motion(O, synth):
+    """the extension of SURVEY 8(f) row 5 on an analytic scene: a textured plane seen from two poses (the second view is the
+    plane-induced homography of the first).  From the identity the alignment recovers rotation to 1e-4 and translation to 1 %"""
+    w, h = 640, 400
+    K = np.array([[718.856, 0, 319.5], [0, 718.856, 199.5], [0, 0, 1.0]])
+    R = synth.rodrigues([0.004, -0.006, 0.003]); t = np.array([0.05, -0.02, 0.30])
+    A, B, H = synth.plane_scene(w, h, K, R, t)
+    uv = synth.grid_points(w, h, 30, border=24)
+    xyz = synth.plane_points(uv, K)
+    # the scene is consistent: the 3-D points project through (R, t) where the homography sends their pixels
+    p2 = (K @ (R @ xyz.T.astype(np.float64) + t[:, None])); p2 = (p2[:2] / p2[2]).T
+    ph = (H @ np.c_[uv, np.ones(len(uv))].T); ph = (ph[:2] / ph[2]).T
+    assert np.abs(p2 - ph).max() < 1e-3
+    pa = O.align_params(K[0, 0], K[1, 1], K[0, 2], K[1, 2], max_level=4, min_level=1, n_iter=12, eps=1e-9)
+    T, n_meas, chi2, iters = O.sparse_align(O.lk_pyramid(A, 5), O.lk_pyramid(B, 5), xyz, pa)
+    assert np.abs(T[:, :3] - R).max() < 1e-4 and np.abs(T[:, 3] - t).max() < 3e-3, T
+    assert n_meas > 0.9 * 16 * len(uv) and chi2 < 2.0 and iters[0] == 0 and all(iters[1:5] > 0)
+    # identical frames: zero residual, the pose stays the identity
+    T0, n0, c0, it0 = O.sparse_align(O.lk_pyramid(A, 5), O.lk_pyramid(A, 5), xyz, pa)
+    assert c0 == 0 and np.abs(T0 - np.eye(3, 4)).max() < 1e-12
