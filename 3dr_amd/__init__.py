@@ -69,15 +69,41 @@ class WarpJob(C.Structure):
                 ("M", C.c_float * 9)]
 
 
+def source_hash():
+    """sha256 over the sources libdr3hip.so is built from (3dr_amd/csrc/*.{hip,cpp,h}, its Makefile, include/dr3hip.h)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) and f != "build_stamp.h") + ["Makefile"]
+    for f in files:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(HEADER, "rb").read())
+    return h.hexdigest()[:20]
+
+
 def build(force=False, extra=""):
-    """Compile every HIP source into 3dr_amd/libdr3hip.so (hipcc --offload-arch=gfx950)."""
+    """Compile every HIP source into 3dr_amd/libdr3hip.so (hipcc --offload-arch=gfx950) and PROVE it: the library carries the
+    hash of the sources it was built from (build_stamp.h -> dr3hip_build_info()); a stale library cannot pass for a fresh one."""
+    stamp, want = os.path.join(CSRC, "build_stamp.h"), '#define DR3HIP_SOURCE_HASH "%s"\n' % source_hash()
+    if not os.path.exists(stamp) or open(stamp).read() != want:
+        open(stamp, "w").write(want)                # newer than dr3hip_api.o -> make recompiles it and relinks
     cmd = ["make", "-C", CSRC, "-j4"]
     if extra:
         cmd.append("EXTRA=" + extra)
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+        open(stamp, "w").write(want)
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    built = built_from()
+    if built != source_hash():
+        raise Dr3HipError("libdr3hip.so reports sources %s, the tree holds %s: the build did not produce the library" % (built, source_hash()))
     return LIB_PATH
+
+
+def built_from():
+    """the source hash the library on disk was built from (read through a fresh handle, no GPU needed)"""
+    L = C.CDLL(LIB_PATH)
+    L.dr3hip_build_info.restype = C.c_char_p
+    return L.dr3hip_build_info().decode()
 
 
 _lib = None
@@ -90,6 +116,7 @@ def _signatures():
     P = C.POINTER
     return {
         "dr3hip_version": ([], ip),
+        "dr3hip_build_info": ([], C.c_char_p),
         "dr3hip_lk_params_reference": ([P(LKParams)], None),
         "dr3hip_device_count": ([], ip),
         "dr3hip_init": ([ip, P(vp)], ip),

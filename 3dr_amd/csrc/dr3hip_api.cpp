@@ -3,6 +3,7 @@
 // Compiled by hipcc as host code (-ffp-contract=off: the homography inversion below must round
 // like cv::invert does on the reference's x86-64 build).
 #include "dr3hip_internal.h"
+#include "build_stamp.h"
 #include <algorithm>
 #include <cmath>
 #include <dlfcn.h>
@@ -150,6 +151,7 @@ static void prof_drain(dr3hip_ctx* ctx)
 extern "C" {
 
 int dr3hip_version(void) { return DR3HIP_VERSION; }
+const char* dr3hip_build_info(void) { return DR3HIP_SOURCE_HASH; }
 
 void dr3hip_lk_params_reference(dr3hip_lk_params* p)
 {

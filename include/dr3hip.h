@@ -77,6 +77,8 @@ void dr3hip_lk_params_reference(dr3hip_lk_params* p);
 
 /* ---- context ------------------------------------------------------------------------------ */
 int         dr3hip_version(void);
+/* hash of the sources (3dr_amd/csrc, include/) this library was built from; "unstamped" for a plain `make` */
+const char* dr3hip_build_info(void);
 int         dr3hip_device_count(void);                       /* 0 when no GPU is visible */
 int         dr3hip_init(int device, dr3hip_ctx** out);
 void        dr3hip_destroy(dr3hip_ctx* ctx);

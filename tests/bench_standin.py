@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH = range(10)
+PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH, PROF_ALIGN = range(11)
 COMM_ID_BYTES = 128
 STEP_SECONDS = 0.01
 

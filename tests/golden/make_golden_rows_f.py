@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates tests/golden/hotpath_rows_f.npz: SELF-golden vectors (oracle inputs + outputs, see make_golden.py for why) of the
 rows added around the path -- FAST-10 grid detector, fused panorama paste + normalise, stitch compose, spherical /
-cylindrical pre-warp, CheckFundamental.  Run from the repo root:  python tests/golden/make_golden_rows_f.py"""
+cylindrical pre-warp, CheckFundamental, Normalize, sparse image alignment.  Run from the repo root:  python tests/golden/make_golden_rows_f.py"""
 import importlib
 import os
 import sys
@@ -57,6 +57,17 @@ def main():
     res = [O.check_fundamental(F, p1, p2, 1.5) for F in Fs]
     out["cf_scores"] = np.array([r[0] for r in res], np.float32)
     out["cf_inliers"] = np.stack([r[1] for r in res])
+    # InitHelper::Normalize (row f4) and the sparse image alignment (row f5, an extension specified by this build)
+    out["norm_xy"], out["norm_T"] = O.normalize_points(p1)
+    Ka = np.array([[300.0, 0, 119.5], [0, 300.0, 79.5], [0, 0, 1.0]])
+    Ra, ta = synth.rodrigues([0.003, -0.004, 0.002]), np.array([0.04, -0.02, 0.15])
+    al_ref, al_cur, _ = synth.plane_scene(240, 160, Ka, Ra, ta, d=8.0)
+    al_uv = synth.grid_points(240, 160, 20, border=16)
+    al_xyz = synth.plane_points(al_uv, Ka, d=8.0)
+    out["al_ref"], out["al_cur"], out["al_xyz"] = al_ref, al_cur, al_xyz
+    pa = O.align_params(300.0, 300.0, 119.5, 79.5, max_level=3, min_level=1, n_iter=10, eps=1e-9)
+    aT, an, ac, ai = O.sparse_align(O.lk_pyramid(al_ref, 4), O.lk_pyramid(al_cur, 4), al_xyz, pa)
+    out["al_T"], out["al_n"], out["al_chi2"], out["al_iters"] = aT, np.int32(an), np.float32(ac), ai
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hotpath_rows_f.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays;", int((lv >= 0).sum()), "features")

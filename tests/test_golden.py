@@ -96,6 +96,12 @@ def test_oracle_reproduces_golden_rows_f(O):
     for k, Fk in enumerate(F["cf_F"]):
         s, inl = O.check_fundamental(Fk, F["cf_p1"], F["cf_p2"], 1.5)
         assert s.view(np.uint32) == F["cf_scores"][k].view(np.uint32) and np.array_equal(inl, F["cf_inliers"][k])
+    nxy, nT = O.normalize_points(F["cf_p1"])
+    assert np.array_equal(_bits(nxy), _bits(F["norm_xy"])) and np.array_equal(_bits(nT), _bits(F["norm_T"]))
+    pa = O.align_params(300.0, 300.0, 119.5, 79.5, max_level=3, min_level=1, n_iter=10, eps=1e-9)
+    aT, an, ac, ai = O.sparse_align(O.lk_pyramid(F["al_ref"], 4), O.lk_pyramid(F["al_cur"], 4), F["al_xyz"], pa)
+    assert np.array_equal(aT.view(np.uint64), F["al_T"].view(np.uint64)) and an == F["al_n"] and np.array_equal(ai, F["al_iters"])
+    assert np.float32(ac).view(np.uint32) == F["al_chi2"].view(np.uint32)
 
 
 def test_host_geometry_reproduces_golden_rows_f(dr3):
@@ -122,3 +128,19 @@ def test_hip_reproduces_golden_rows_f(dr3, ctx):
     assert np.array_equal(ctx.warp_cylindrical(F["pano_tiles"][0], 95.5), F["cyl"])
     scores, inl = ctx.check_fundamental(F["cf_F"], F["cf_p1"], F["cf_p2"], 1.5)
     assert np.array_equal(_bits(scores), _bits(F["cf_scores"])) and np.array_equal(inl, F["cf_inliers"])
+    nxy, nT = ctx.normalize_points(F["cf_p1"])
+    assert np.array_equal(_bits(nxy), _bits(F["norm_xy"])) and np.array_equal(_bits(nT), _bits(F["norm_T"]))
+    b = dr3.FrameBatch(ctx, 240, 160, win=(15, 15), max_level=3, capacity=2)
+    d_xyz, d_T = ctx.to_device(F["al_xyz"]), ctx.to_device(np.eye(3, 4))
+    d_n, d_c, d_i = ctx.alloc(4), ctx.alloc(4), ctx.alloc(32)
+    try:
+        b.upload(0, np.stack([F["al_ref"], F["al_cur"]])); b.build(0, 2, True)
+        b.align(1, 0, d_xyz, len(F["al_xyz"]), dr3.align_params(300.0, 300.0, 119.5, 79.5, max_level=3, min_level=1, n_iter=10, eps=1e-9), d_T, d_n, d_c, d_i)
+        ctx.sync()
+        assert np.array_equal(d_T.download((3, 4), np.float64).view(np.uint64), F["al_T"].view(np.uint64))
+        assert d_n.download((1,), np.int32)[0] == F["al_n"] and np.array_equal(d_i.download((8,), np.int32)[:4], F["al_iters"])
+        assert d_c.download((1,), np.float32).view(np.uint32)[0] == F["al_chi2"].view(np.uint32)
+    finally:
+        for d in (d_xyz, d_T, d_n, d_c, d_i):
+            d.free()
+        b.close()
