@@ -132,6 +132,7 @@ __global__ __launch_bounds__(AL_LANES) void sparse_align_kernel(const AlignArgs 
     for (int i = 0; i < 12; ++i) { T[i] = a.T[12ll * pair + i]; T_old[i] = T[i]; }
     int n_meas = 0;
     float chi2_last = 0.f;
+    if (a.iters && tid < DR3HIP_MAX_LEVELS) a.iters[(long long)pair * DR3HIP_MAX_LEVELS + tid] = 0;     // levels that do not run report 0
 
     for (int level = a.max_level; level >= a.min_level; --level) {
         const LevelDev& L = a.lv[level];

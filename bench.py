@@ -619,7 +619,7 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
     for name, kw, kernel in cases:
         b = dr3.FrameBatch(ctx, W_, H_, win=kw["win"], max_level=kw["max_level"], capacity=NP + 1)
         for s0 in range(0, NP + 1, 64):
-            b.upload(s0, np.stack(frames[s0:s0 + 64]))
+            b.upload(s0, np.stack(frames[s0:min(s0 + 64, NP + 1)]))
         b.build(0, NP + 1, True)
         d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
         d_st, d_err = ctx.alloc(NP * n), ctx.alloc(NP * n * 4)
