@@ -480,35 +480,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPASS == 1 ?
 
 
 // =====================================================================================================================
-// Two points per wave: windows of at most 32 lane-items of 8 taps (win_w <= 16, ceil(win_w / 8) * win_h <= 32: every window up to
-// 16x16, the bench's 15x15 among them).  Half a wave (32 lanes = DPP rows 0-1 or rows 2-3) owns one point; lane-item
-// q = ty * ceil(win_w / 8) + r covers the 8 taps (ty, 8r .. 8r+7).  Everything that is wave-uniform in the kernel above
-// -- window origins, bilinear weights, the 2x2 solve, the exit tests, the reductions' tails -- is computed once per
-// wave-instruction for TWO points; the per-tap work per point is unchanged.  The halves run in lock step: a level / an
-// iteration is executed while either point needs it (consecutive points of a frame take the same number of iterations
-// within 8 % on the bench's stream), a point that is done sits the rest out under an exec mask, and every cross-lane
-// instruction runs in wave-uniform control flow with all 64 lanes enabled (v_permlane16_swap and the DPP row operations
-// never cross the half-wave boundary).
+// Several points per wave, for the small windows (every window up to 16x16, the bench's 15x15 among them).
+//   PPW = 4: win_w <= 16 and win_h <= 16.  A quarter wave (16 lanes = one DPP row) owns one point; a lane owns one window row
+//            of up to 16 taps.
+//   PPW = 2: the other windows of at most 32 lane-items of 8 taps (win_w <= 16, ceil(win_w / 8) * win_h <= 32, e.g. 8x32): half
+//            a wave (DPP rows 0-1 or 2-3) owns one point; lane-item q = ty * ceil(win_w / 8) + r covers the 8 taps (ty, 8r .. 8r+7).
+// Everything that is wave-uniform in the whole-wave kernel above -- window origins, bilinear weights, the 2x2 solve, the exit
+// tests, the reductions' tails -- is computed once per wave-instruction for PPW points; the per-tap work per point is unchanged.
+// The groups run in lock step: a level / an iteration is executed while any point of the wave needs it (consecutive points of a
+// frame take the same number of iterations within a few per cent on the bench's stream), a point that is done sits the rest out
+// under an exec mask, and every cross-lane instruction runs in wave-uniform control flow with all 64 lanes enabled
+// (v_permlane16_swap and the DPP row operations never leave a group).
 // Addressing: every level of a frame batch carries OpenCV's winSize border physically (LevelDev::pad_x / pad_y,
 // REFLECT_101 pixels written by pad_reflect_kernel, zero derivatives), so every window that passes the bounds test is
 // plain memory: one wave-uniform plane base in SGPRs + an unsigned 32-bit lane offset (global_load ... v, s[base]), no
 // reflection code at all.
-// Summation order (oracle DR3O_ORDER_WAVE64 for these windows): the <= 8 taps of a lane are summed exactly in int32,
-// converted to f32 once into p[l] (l < 32); c[l] = p[l] + p[l+16]; xor butterfly 1,2,4,8 over the 16 values.
+// Summation order (the checker's kernel order for these windows): the taps of a lane are summed exactly in int32, converted to
+// f32 once into p[l]; PPW = 2: c[l] = p[l] + p[l+16] (l < 16); both: xor butterfly 1,2,4,8 over the 16 values.
 // =====================================================================================================================
 
-// sums over each half-wave of two / three lane values; every lane receives its own half's totals
-__device__ __forceinline__ void half_sum2(float a, float b, float& ra, float& rb)
+// sums over each group of two / three lane values; every lane receives its own group's totals
+template <int PPW>
+__device__ __forceinline__ void group_sum2(float a, float b, float& ra, float& rb)
 {
+    if (PPW == 4) { ra = row_butterfly(a); rb = row_butterfly(b); return; }
     const float v = row_butterfly(fold16(a, b));                 // row totals: a.A  b.A | a.B  b.B
     const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     ra = __uint_as_float(sw[0]);                                 // a.A  a.A | a.B  a.B
     rb = __uint_as_float(sw[1]);                                 // b.A  b.A | b.B  b.B
 }
-__device__ __forceinline__ void half_sum3(float a, float b, float c, float& ra, float& rb, float& rc)
+template <int PPW>
+__device__ __forceinline__ float group_sum1(float c)
 {
-    half_sum2(a, b, ra, rb);
-    rc = row_butterfly(fold16(c, c));                            // c.A  c.A | c.B  c.B
+    return PPW == 4 ? row_butterfly(c) : row_butterfly(fold16(c, c));
 }
 
 // wave-uniform global base + unsigned 32-bit lane offset: selects the saddr form of global_load
@@ -525,34 +529,36 @@ __device__ __forceinline__ gbase_t as_global(const void* p)
     return (gbase_t)(const uint8_t*)p;
 }
 
-// three aligned dwords of two image rows; tap k (0..7) uses bytes o+k, o+k+1 of the 12-byte window: taps 0-3 work on
-// dwords (0,1), taps 4-7 on dwords (1,2), with the same four selectors
-struct Rows3 { uint32_t a0, a1, a2, b0, b1, b2; };
-template <int K>
-__device__ __forceinline__ Rows rows_of(const Rows3& r)
+// the two aligned dword pairs tap K of a lane-item works on: taps 4j .. 4j+3 use dwords (j, j+1) of both rows, all with the same
+// four byte selectors
+template <int ND>
+__device__ __forceinline__ Rows rows_of(const uint32_t (&ra)[ND], const uint32_t (&rb)[ND], int j)
 {
-    Rows o;
-    if (K < 4) { o.lo0 = r.a0; o.hi0 = r.a1; o.lo1 = r.b0; o.hi1 = r.b1; }
-    else       { o.lo0 = r.a1; o.hi0 = r.a2; o.lo1 = r.b1; o.hi1 = r.b2; }
+    Rows o; o.lo0 = ra[j]; o.hi0 = ra[j + 1]; o.lo1 = rb[j]; o.hi1 = rb[j + 1];
     return o;
 }
 
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-#ifndef LK2_WAVES
-#define LK2_WAVES 4
+#ifndef LKG_WAVES
+#define LKG_WAVES 4
 #endif
-// WIN > 0: square compile-time window (<= 16); WIN = 0: any window with win_w <= 16 and ceil(win_w / 8) * win_h <= 32
-template <int WIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES))) void lk_track2_kernel(const LKArgs a)
+// WIN > 0: square compile-time window (<= 16); WIN = 0: run-time window fitting PPW (see above)
+template <int WIN, int PPW>
+// (the run-time 16-tap form needs more registers than four waves per SIMD leave it)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PPW == 4 && WIN == 0) ? 3 : LKG_WAVES))) void lk_trackg_kernel(const LKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    constexpr int LANES = 64 / PPW;               // lanes per point
+    constexpr int NT = PPW == 4 ? 16 : 8;         // taps per lane-item
+    constexpr int ND = NT / 4 + 1;                // aligned dwords of an image row a lane-item reads
+    constexpr int SR = LANES / 8;                 // rows a group stages per round (8 dword columns)
 
-    const int lane = threadIdx.x, hl = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x, hl = lane & (LANES - 1), grp = lane / LANES;
     const int pair = blockIdx.y;
-    const int pt_raw = 2 * blockIdx.x + half;
+    const int pt_raw = PPW * blockIdx.x + grp;
     const bool pt_ok = pt_raw < a.n_pts;
-    const int pt = pt_ok ? pt_raw : a.n_pts - 1;          // an odd point count: the spare half shadows the last point, stores nothing
+    const int pt = pt_ok ? pt_raw : a.n_pts - 1;          // a spare group shadows the last point and stores nothing
     const long long pidx = (long long)pair * a.n_pts + pt;
     const int ps = a.prev_slot ? a.prev_slot[pair] : a.first_slot + pair;
     const int ns = a.next_slot ? a.next_slot[pair] : a.first_slot + pair + 1;
@@ -561,32 +567,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
-    const int rpr8 = (win_w + 7) >> 3;                     // 1 or 2
-    const int rwd = 2 * rpr8 + 3, rh = win_h + 9, lpd = rwd | 1;
-    const int rh4 = (rh + 3) & ~3;                         // LDS rows per slice: staging runs in rounds of 4 rows
-    const int n_items = rpr8 * win_h;
+    const int rpr = PPW == 4 ? 1 : (win_w + 7) >> 3;       // lane-items per window row
+    const int rwd = win_w > 8 ? 7 : 5, rh = win_h + 9, lpd = rwd;      // staged J region: dwords per row (odd), rows
+    const int rhs = (rh + SR - 1) / SR * SR;               // LDS rows per slice: staging runs in rounds of SR rows
+    const int n_items = rpr * win_h;
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
-    uint32_t* __restrict__ lds = lds_all + half * (rh4 * lpd);
+    uint32_t* __restrict__ lds = lds_all + grp * (rhs * lpd);
 
     // lane-item geometry; lanes beyond the last item shadow item 0 with all-zero masks
     const bool ivalid = hl < n_items;
-    const int r8 = (rpr8 == 2 && ivalid) ? (hl & 1) : 0;
-    const int ity = ivalid ? (rpr8 == 2 ? hl >> 1 : hl) : 0;
+    const int r8 = (PPW == 2 && rpr == 2 && ivalid) ? (hl & 1) : 0;
+    const int ity = ivalid ? ((PPW == 2 && rpr == 2) ? hl >> 1 : hl) : 0;
     const int itx = 8 * r8;
     const uint32_t loffB = (uint32_t)(ity * lpd + 2 * r8) * 4u;      // byte offset of the lane-item inside a staged region
-    const int ntap = ivalid ? win_w - itx : 0;             // taps of this item inside the window (1..8), 0 for idle lanes
-    uint32_t mk[4];                                        // int16-pair masks: taps (2h, 2h+1)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) mk[h] = ntap >= 2 * h + 2 ? 0xffffffffu : (ntap == 2 * h + 1 ? 0x0000ffffu : 0u);
-    // staging grid of the half: 4 rows x 8 dword columns per round
-    const int sc = hl & 7, sr = (hl >> 3) & 3;
+    const int ntap = ivalid ? win_w - itx : 0;             // taps of this item inside the window, 0 for idle lanes
+    // int16-pair mask of taps (2h, 2h+1): all ones, the low half only, or nothing
+    auto pair_mask = [ntap](int h) -> uint32_t { return ntap >= 2 * h + 2 ? 0xffffffffu : (ntap == 2 * h + 1 ? 0x0000ffffu : 0u); };
+    // staging grid of the group: SR rows x 8 dword columns per round
+    const int sc = hl & 7, sr = hl >> 3;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;
 
     int   status = 1;
     float err = 0.f;
-    int Ib[8];
-    uint32_t Ix[4], Iy[4];
+    int Ib[NT];
+    uint32_t Ix[NT / 2], Iy[NT / 2];
 
     for (int level = a.max_level; level >= 0; --level) {
         const LevelDev& L = a.lv[level];
@@ -625,23 +630,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
         // ---- stage the J search region around the starting estimate: rows [sy-RM, sy-RM+rh) x aligned byte columns
         // [x0, x0 + 4*rwd).  A start outside the level is rejected by the first iteration's bounds test; the staging
         // centre is clamped so that the (unused) region stays inside the padded plane.
-        int rx0, ry0;                      // interior coordinates of LDS (row 0, byte 0) of this half's region; rx0 is a multiple of 4
+        int rx0, ry0;                      // interior coordinates of LDS (row 0, byte 0) of this group's region; rx0 is a multiple of 4
         {
             const int sx = floor_to_int(floorf(cx)), sy = floor_to_int(floorf(cy));
             const int cxs = min(max(sx, -win_w), Lw - 1), cys = min(max(sy, -win_h), Lh - 1);
             rx0 = (cxs - RM) & ~3;
             ry0 = cys - RM;
             uint32_t off = __umul24((unsigned)(ry0 + pad_y + sr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 4 * sc);
-            const uint32_t step = 4u * (unsigned)pitch;
+            const uint32_t step = (uint32_t)SR * (unsigned)pitch;
             if (sc < rwd) {
                 if (WIN) {
 #pragma unroll
-                    for (int k = 0; k < (WIN + 9 + 3) / 4; ++k) {
-                        if (4 * k + 3 < WIN + 9 || sr + 4 * k < rh) lds_st[4 * k * lpd] = ldg<uint32_t>(Jbase, off);
+                    for (int k = 0; k < (WIN + 9 + SR - 1) / SR; ++k) {
+                        if (SR * k + SR - 1 < WIN + 9 || sr + SR * k < rh) lds_st[SR * k * lpd] = ldg<uint32_t>(Jbase, off);
                         off += step;
                     }
                 } else {
-                    for (int r = sr; r < rh; r += 4) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += step; }
+                    for (int r = sr; r < rh; r += SR) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += step; }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -656,30 +661,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
             const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
             const uint32_t offI = __umul24((unsigned)yp, (unsigned)pitch) + ((unsigned)xp & ~3u);
             const uint32_t offD = __umul24((unsigned)yp, (unsigned)dpitch) + 4u * (unsigned)xp;
-            const u32x3 ra = ldg<u32x3>(Ibase, offI), rb = ldg<u32x3>(Ibase, offI + (unsigned)pitch);
-            // packed (Ix | Iy<<16) of rows y, y+1, columns x..x+8
-            const u32x4 da0 = ldg<u32x4>(Dbase, offD), da1 = ldg<u32x4>(Dbase, offD + 16u);
-            const uint32_t da2 = ldg<uint32_t>(Dbase, offD + 32u);
-            const u32x4 db0 = ldg<u32x4>(Dbase, offD + (unsigned)dpitch), db1 = ldg<u32x4>(Dbase, offD + (unsigned)dpitch + 16u);
-            const uint32_t db2 = ldg<uint32_t>(Dbase, offD + (unsigned)dpitch + 32u);
-            const uint32_t d0[9] = {da0.x, da0.y, da0.z, da0.w, da1.x, da1.y, da1.z, da1.w, da2};
-            const uint32_t d1[9] = {db0.x, db0.y, db0.z, db0.w, db1.x, db1.y, db1.z, db1.w, db2};
-            Rows3 r; r.a0 = ra.x; r.a1 = ra.y; r.a2 = ra.z; r.b0 = rb.x; r.b1 = rb.y; r.b2 = rb.z;
-            const Rows rl = rows_of<0>(r), ru = rows_of<4>(r);
+            uint32_t ra[ND], rb[ND];             // image rows y, y+1 as aligned dwords
+            uint32_t d0[NT + 1], d1[NT + 1];     // packed (Ix | Iy<<16) of rows y, y+1, columns x .. x+NT
+            if (PPW == 4) {
+                const u32x4 a4 = ldg<u32x4>(Ibase, offI), b4 = ldg<u32x4>(Ibase, offI + (unsigned)pitch);
+                ra[0] = a4.x; ra[1] = a4.y; ra[2] = a4.z; ra[3] = a4.w; ra[ND - 1] = ldg<uint32_t>(Ibase, offI + 16u);
+                rb[0] = b4.x; rb[1] = b4.y; rb[2] = b4.z; rb[3] = b4.w; rb[ND - 1] = ldg<uint32_t>(Ibase, offI + (unsigned)pitch + 16u);
+            } else {
+                const u32x3 a3 = ldg<u32x3>(Ibase, offI), b3 = ldg<u32x3>(Ibase, offI + (unsigned)pitch);
+                ra[0] = a3.x; ra[1] = a3.y; ra[2] = a3.z; rb[0] = b3.x; rb[1] = b3.y; rb[2] = b3.z;
+            }
+#pragma unroll
+            for (int q = 0; q < NT / 4; ++q) {
+                const u32x4 u = ldg<u32x4>(Dbase, offD + 16u * q), v = ldg<u32x4>(Dbase, offD + (unsigned)dpitch + 16u * q);
+                d0[4 * q] = u.x; d0[4 * q + 1] = u.y; d0[4 * q + 2] = u.z; d0[4 * q + 3] = u.w;
+                d1[4 * q] = v.x; d1[4 * q + 1] = v.y; d1[4 * q + 2] = v.z; d1[4 * q + 3] = v.w;
+            }
+            d0[NT] = ldg<uint32_t>(Dbase, offD + 4u * NT);
+            d1[NT] = ldg<uint32_t>(Dbase, offD + (unsigned)dpitch + 4u * NT);
             // every tap is computed; taps beyond the window's last column (and idle lanes) get zero gradients through the
             // pair masks, which removes them from every sum
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < NT / 2; ++h) {
                 int gx[2], gy[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int k = 2 * h + t;
                     const uint32_t sel = (k & 3) == 0 ? sel0 : (k & 3) == 1 ? sel1 : (k & 3) == 2 ? sel2 : sel3;
-                    Ib[k] = BILIN_ROUND - (bilin_u8(k < 4 ? rl : ru, sel, W, BILIN_ROUND) << (W_BITS - 5));
+                    Ib[k] = BILIN_ROUND - (bilin_u8(rows_of<ND>(ra, rb, k >> 2), sel, W, BILIN_ROUND) << (W_BITS - 5));
                     gx[t] = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
                     gy[t] = bilin_s16<0x07060302u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
                 }
-                const uint32_t x2 = pack_s16(gx[0], gx[1]) & mk[h], y2 = pack_s16(gy[0], gy[1]) & mk[h];
+                const uint32_t mkh = pair_mask(h);
+                const uint32_t x2 = pack_s16(gx[0], gx[1]) & mkh, y2 = pack_s16(gy[0], gy[1]) & mkh;
                 Ix[h] = x2; Iy[h] = y2;
                 s11 = dot_s16(x2, x2, s11);
                 s12 = dot_s16(x2, y2, s12);
@@ -687,7 +701,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
             }
         }
         float A11, A12, A22;
-        half_sum3((float)s11, (float)s12, (float)s22, A11, A12, A22);
+        group_sum2<PPW>((float)s11, (float)s12, A11, A12);
+        A22 = group_sum1<PPW>((float)s22);
         A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
 
         float D = A11 * A22 - A12 * A12;
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
         }
         D = 1.f / D;
 
-        // ---- Gauss-Newton iterations (out of LDS), both points in lock step ---------------------------
+        // ---- Gauss-Newton iterations (out of LDS), all points of the wave in lock step -------------------------
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; ++j) {
             float fcx = 0.f, fcy = 0.f;
@@ -726,7 +741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
                     ry0 = iny - RM;
                     uint32_t off = __umul24((unsigned)(ry0 + pad_y + sr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 4 * sc);
                     if (sc < rwd)
-                        for (int r = sr; r < rh; r += 4) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += 4u * (unsigned)pitch; }
+                        for (int r = sr; r < rh; r += SR) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += (uint32_t)SR * (unsigned)pitch; }
                     __builtin_amdgcn_wave_barrier();
                     dxb = (uint32_t)((inx & ~3) - rx0); dyr = (uint32_t)(iny - ry0);
                 }
@@ -734,17 +749,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
                 const uint32_t o = (uint32_t)inx & 3u;
                 const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (__umul24(dyr, (unsigned)(4 * lpd)) + dxb + loffB));
-                Rows3 r; r.a0 = p[0]; r.a1 = p[1]; r.a2 = p[2]; r.b0 = p[lpd]; r.b1 = p[lpd + 1]; r.b2 = p[lpd + 2];
-                const Rows rl = rows_of<0>(r), ru = rows_of<4>(r);
-                const uint32_t m01 = pack_s16(bilin_u8(rl, sel0, W, Ib[0]), bilin_u8(rl, sel1, W, Ib[1]));
-                const uint32_t m23 = pack_s16(bilin_u8(rl, sel2, W, Ib[2]), bilin_u8(rl, sel3, W, Ib[3]));
-                const uint32_t m45 = pack_s16(bilin_u8(ru, sel0, W, Ib[4]), bilin_u8(ru, sel1, W, Ib[5]));
-                const uint32_t m67 = pack_s16(bilin_u8(ru, sel2, W, Ib[6]), bilin_u8(ru, sel3, W, Ib[7]));
-                s1 = dot_s16(m01, Ix[0], s1); s1 = dot_s16(m23, Ix[1], s1); s1 = dot_s16(m45, Ix[2], s1); s1 = dot_s16(m67, Ix[3], s1);
-                s2 = dot_s16(m01, Iy[0], s2); s2 = dot_s16(m23, Iy[1], s2); s2 = dot_s16(m45, Iy[2], s2); s2 = dot_s16(m67, Iy[3], s2);
+                uint32_t ra[ND], rb[ND];
+#pragma unroll
+                for (int q = 0; q < ND; ++q) { ra[q] = p[q]; rb[q] = p[lpd + q]; }
+#pragma unroll
+                for (int h = 0; h < NT / 2; ++h) {
+                    const Rows r = rows_of<ND>(ra, rb, h >> 1);
+                    const uint32_t m = (h & 1) ? pack_s16(bilin_u8(r, sel2, W, Ib[2 * h]), bilin_u8(r, sel3, W, Ib[2 * h + 1]))
+                                               : pack_s16(bilin_u8(r, sel0, W, Ib[2 * h]), bilin_u8(r, sel1, W, Ib[2 * h + 1]));
+                    s1 = dot_s16(m, Ix[h], s1);
+                    s2 = dot_s16(m, Iy[h], s2);
+                }
             }
             float b1, b2;
-            half_sum2((float)s1, (float)s2, b1, b2);
+            group_sum2<PPW>((float)s1, (float)s2, b1, b2);
             if (act) {
                 b1 *= FLT_SCALE; b2 *= FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * D;
@@ -778,7 +796,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
                     ry0 = iny - RM;
                     uint32_t off = __umul24((unsigned)(ry0 + pad_y + sr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 4 * sc);
                     if (sc < rwd)
-                        for (int r = sr; r < rh; r += 4) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += 4u * (unsigned)pitch; }
+                        for (int r = sr; r < rh; r += SR) { lds_st[(r - sr) * lpd] = ldg<uint32_t>(Jbase, off); off += (uint32_t)SR * (unsigned)pitch; }
                     __builtin_amdgcn_wave_barrier();
                     dxb = (uint32_t)((inx & ~3) - rx0); dyr = (uint32_t)(iny - ry0);
                 }
@@ -786,18 +804,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
                 const uint32_t o = (uint32_t)inx & 3u;
                 const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (__umul24(dyr, (unsigned)(4 * lpd)) + dxb + loffB));
-                Rows3 r; r.a0 = p[0]; r.a1 = p[1]; r.a2 = p[2]; r.b0 = p[lpd]; r.b1 = p[lpd + 1]; r.b2 = p[lpd + 2];
-                const Rows rl = rows_of<0>(r), ru = rows_of<4>(r);
-                // sum of |mismatch| over the taps inside the window: |d| <= 2^13 packed in int16 pairs, dotted with the pair
-                // masks reduced to ones (exact integer sum of at most 8 taps)
+                uint32_t ra[ND], rb[ND];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const uint32_t sa = (2 * h & 3) == 0 ? sel0 : sel2, sb = (2 * h & 3) == 0 ? sel1 : sel3;
-                    const int da = bilin_u8(h < 2 ? rl : ru, sa, W, Ib[2 * h]), db = bilin_u8(h < 2 ? rl : ru, sb, W, Ib[2 * h + 1]);
-                    se = dot_s16(pack_s16(da < 0 ? -da : da, db < 0 ? -db : db), mk[h] & 0x00010001u, se);
+                for (int q = 0; q < ND; ++q) { ra[q] = p[q]; rb[q] = p[lpd + q]; }
+                // sum of |mismatch| over the taps inside the window: |d| <= 2^13 packed in int16 pairs, dotted with the pair
+                // masks reduced to ones (exact integer sum of at most NT taps)
+#pragma unroll
+                for (int h = 0; h < NT / 2; ++h) {
+                    const Rows r = rows_of<ND>(ra, rb, h >> 1);
+                    const int da = bilin_u8(r, (h & 1) ? sel2 : sel0, W, Ib[2 * h]), db = bilin_u8(r, (h & 1) ? sel3 : sel1, W, Ib[2 * h + 1]);
+                    se = dot_s16(pack_s16(da < 0 ? -da : da, db < 0 ? -db : db), pair_mask(h) & 0x00010001u, se);
                 }
             }
-            const float tot = row_butterfly(fold16((float)se, (float)se));
+            const float tot = group_sum1<PPW>((float)se);
             if (res) err = tot * 1.f / (float)(32 * win_w * win_h);
         }
     }
@@ -812,18 +831,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK2_WAVES)))
 
 }  // namespace
 
-// windows the two-points-per-wave kernel takes (the oracle's kernel_order_is_half_wave is the same rule)
-static inline bool lk_half_wave_window(int win_w, int win_h) { return win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32; }
+// points per wave by window (the CPU checker's summation-order rule is the same): 4 for windows up to 16 x 16, 2 for the other
+// windows of at most 32 lane-items of 8 taps, 1 (the whole-wave kernel) beyond
+static inline int lk_points_per_wave(int win_w, int win_h)
+{
+    if (win_w <= 16 && win_h <= 16) return 4;
+    if (win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32) return 2;
+    return 1;
+}
 
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
 {
     if (n_pairs <= 0 || a.n_pts <= 0) return hipSuccess;
-    if (lk_half_wave_window(a.win_w, a.win_h)) {
-        const int rwd = 2 * ((a.win_w + 7) / 8) + 3, rh4 = (a.win_h + 9 + 3) & ~3, lpd = rwd | 1;
-        dim3 grid((a.n_pts + 1) / 2, n_pairs), block(64);
-        const size_t shmem = (size_t)2 * rh4 * lpd * sizeof(uint32_t);
-        if (a.win_w == 15 && a.win_h == 15) hipLaunchKernelGGL((lk_track2_kernel<15>), grid, block, shmem, s, a);
-        else hipLaunchKernelGGL((lk_track2_kernel<0>), grid, block, shmem, s, a);
+    const int ppw = lk_points_per_wave(a.win_w, a.win_h);
+    if (ppw > 1) {
+        const int sr = 64 / ppw / 8, rwd = a.win_w > 8 ? 7 : 5, rhs = (a.win_h + 9 + sr - 1) / sr * sr;
+        dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
+        const size_t shmem = (size_t)ppw * rhs * rwd * sizeof(uint32_t);
+        if (ppw == 4) {
+            if (a.win_w == 15 && a.win_h == 15) hipLaunchKernelGGL((lk_trackg_kernel<15, 4>), grid, block, shmem, s, a);
+            else hipLaunchKernelGGL((lk_trackg_kernel<0, 4>), grid, block, shmem, s, a);
+        } else {
+            hipLaunchKernelGGL((lk_trackg_kernel<0, 2>), grid, block, shmem, s, a);
+        }
         return hipGetLastError();
     }
     const int npass = (a.n_items + 63) / 64;

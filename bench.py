@@ -171,44 +171,73 @@ def aggregate_rate(dist, units_this_rank, elapsed_max):
 # ----------------------------------------------------------------------------------------------
 # algorithmic bytes
 # ----------------------------------------------------------------------------------------------
+def kernel_source_hash(files):
+    """hash of kernel sources, the stamp tools/summarize_profiles.py and tools/lk_valu_mix.py put on what they record: a profile
+    of an older kernel must not be reported for the one being timed"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "3dr_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(fname, want_hash=None):
+    """newest committed profiles/<round>/<fname> whose source_hash (when the file carries one) matches the sources in the tree"""
+    root = os.path.join(ROOT, "profiles")
+    try:
+        for d in sorted(os.listdir(root), reverse=True):
+            f = os.path.join(root, d, fname)
+            if os.path.exists(f):
+                j = json.load(open(f))
+                if want_hash is None or j.get("source_hash") in (None, want_hash):
+                    return j, "profiles/%s/%s" % (d, fname)
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json"):
     """HBM bytes per launch of one kernel from the newest committed PMC summary (profiles/*/pmc_traffic.json,
     made by tools/profile_bench.sh + tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same script; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).
     PMC counters cannot be collected from inside the process being timed, so the figure is the recorded one
-    for the same launch shape (default --batch); any other shape reports None."""
+    for the same launch shape (default --batch); any other shape, or a summary recorded for other kernel sources, reports None."""
     if batch != 256:
         return None, None
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    try:
-        for d in sorted(os.listdir(root), reverse=True):
-            f = os.path.join(root, d, fname)
-            if os.path.exists(f):
-                for name, t in json.load(open(f))["kernels"].items():
-                    if kernel_substr in name and "hbm_bytes" in t:
-                        return t["hbm_bytes"], "profiles/%s/%s" % (d, fname)
-    except (OSError, ValueError, KeyError):
-        pass
+    j, src = newest_profile(fname, kernel_source_hash(("pyr_kernels.hip", "warp_kernels.hip", "dr3hip_internal.h")))
+    if j:
+        for name, t in j.get("kernels", {}).items():
+            if kernel_substr in name and "hbm_bytes" in t:
+                return t["hbm_bytes"], src
     return None, None
 
 
-def lk_valu_issue(lk_ms, waves):
-    """the tracker against the VALU issue roofline: VALU instructions per wave from the newest committed PMC summary
-    (profiles/*/pmc_lk.json, SQ_INSTS_VALU / SQ_WAVES of this launch shape) x waves / launch time, over 256 CUs x 4 SIMDs x
-    2.4 GHz / 4 clocks per wave64 instruction"""
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    try:
-        for d in sorted(os.listdir(root), reverse=True):
-            f = os.path.join(root, d, "pmc_lk.json")
-            if os.path.exists(f):
-                j = json.load(open(f))
-                ach = j["valu_per_wave"] * waves / (lk_ms * 1e-3) / 1e9
-                peak = 256 * 4 * 2.4e9 / 4 / 1e9
-                return {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
-                        "valu_per_wave": j["valu_per_wave"], "salu_per_wave": j.get("salu_per_wave"), "source": "profiles/%s/pmc_lk.json" % d}
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def lk_valu_issue(lk_ms, waves, kernel):
+    """The tracker against the VALU issue roofline of ITS OWN instruction mix.  gfx950 issues a wave64 VALU instruction in 2, 4
+    or 8 clocks depending on the opcode (tools/ubench/valu_rate.hip, profiles/r02_lk/ubench_valu_rate*.txt), so the ceiling is
+    1024 SIMDs x 2.4 GHz / (average issue clocks of the mix).  VALU instructions per wave: rocprofv3 --pmc SQ_INSTS_VALU /
+    SQ_WAVES of this launch shape (profiles/*/pmc_lk.json); average issue clocks: tools/lk_valu_mix.py on the kernel's ISA
+    (profiles/*/valu_mix.json).  Both files carry the hash of the kernel source they were made from; a mismatch reports None
+    rather than numbers of another kernel."""
+    want = kernel_source_hash(("lk_kernels.hip", "dr3hip_internal.h"))
+    pmc, psrc = newest_profile("pmc_lk.json", want)
+    mix, msrc = newest_profile("valu_mix.json", want)
+    if not pmc or not mix or pmc.get("source_hash") != want or mix.get("source_hash") != want:
+        return None
+    k = next((v for name, v in pmc.get("kernels", {}).items() if kernel in name), None)
+    if not k:
+        return None
+    clk = mix["avg_issue_clocks_per_valu"]
+    n_wave_instr = k["valu_per_wave"] * (waves / k["points_per_wave"])
+    ach = n_wave_instr / (lk_ms * 1e-3) / 1e9
+    peak = 1024 * 2.4 / clk
+    return {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "avg_issue_clocks_per_valu": clk, "valu_per_wave": k["valu_per_wave"], "salu_per_wave": k.get("salu_per_wave"),
+            "points_per_wave": k["points_per_wave"],
+            "valu_pipe_busy_profiled": k.get("valu_issue_busy"), "scalar_pipe_busy_profiled": k.get("salu_issue_busy"),
+            "clock_ghz_profiled": k.get("clock_ghz"), "source": [psrc, msrc],
+            "note": "peak = 1024 SIMDs x 2.4 GHz / avg issue clocks of this kernel's VALU mix (2-clock and 4-clock opcodes measured by "
+                    "tools/ubench/valu_rate.hip); *_busy_profiled = issue clocks / elapsed clocks inside the rocprofv3 run at its own clock"}
 
 
 def level_sizes(w, h, levels):
@@ -456,6 +485,9 @@ def main(argv=None):
         ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
         ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
         traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B)
+        half_wave = WIN <= 16                                          # square windows up to 16x16: four points per wave
+        lk_kernel_name = ("lk_trackg_kernel<%d, 4>" % (WIN if WIN == 15 else 0)) if half_wave else \
+            "lk_track_kernel<%d, %d>" % ((((WIN + 3) // 4) * WIN + 63) // 64, WIN if WIN == 21 else 0)
         out = {
             "metric": "tracked_keypoints_per_sec",
             "value": kps,
@@ -490,11 +522,11 @@ def main(argv=None):
                                        "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": ach_pass / HBM_PEAK_GBPS, "traffic": None,
                                        "algorithmic_bytes_per_pass": b_pass, "avg_pass_ms": pass_ms},
-            "lk_kernel": {"kernel": "lk_track_kernel<%d, %d>" % ((((WIN + 3) // 4) * WIN + 63) // 64, WIN if WIN in (15, 21) else 0), "avg_launch_ms": lk_ms,
+            "lk_kernel": {"kernel": lk_kernel_name, "avg_launch_ms": lk_ms,
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
                           "note": "VALU-issue bound, not HBM-bound (SURVEY 8d): no HBM fraction claimed",
-                          "valu_issue": lk_valu_issue(lk_ms, B * N_PTS) if args.workload == "kitti" else None},
+                          "valu_issue": lk_valu_issue(lk_ms, B * N_PTS, lk_kernel_name) if args.workload == "kitti" else None},
             "hbm_copy_measured_GBps": copy_gbps,
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,

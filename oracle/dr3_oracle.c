@@ -166,16 +166,23 @@ typedef struct {
     float acc[3];
 } wsum;
 
-/* The HIP tracker has two shapes (3dr_amd/csrc/lk_kernels.hip).  Windows of at most 32 lane-items of 8 taps
- * (win_w <= 16 and ceil(win_w / 8) * win_h <= 32: every window up to 16x16, e.g. the bench's 15x15) are tracked by HALF a wave, two points
- * per wave64; larger windows by a whole wave with lane-items of 4 taps.  DR3O_ORDER_WAVE64 follows whichever applies. */
-static int kernel_order_is_half_wave(int win_w, int win_h) { return win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32; }
+/* The HIP tracker has three shapes (3dr_amd/csrc/lk_kernels.hip).  Windows up to 16 x 16 (e.g. the bench's 15x15) are tracked by a
+ * QUARTER of a wave -- 16 lanes, one window row of up to 16 taps per lane, four points per wave64; the other windows of at most 32
+ * lane-items of 8 taps (win_w <= 16, ceil(win_w / 8) * win_h <= 32, e.g. 8x32) by HALF a wave, two points per wave; larger windows
+ * by a whole wave with lane-items of 4 taps.  DR3O_ORDER_WAVE64 follows whichever applies. */
+static int kernel_points_per_wave(int win_w, int win_h)
+{
+    if (win_w <= 16 && win_h <= 16) return 4;
+    if (win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32) return 2;
+    return 1;
+}
 
 static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {
+    const int ppw = kernel_points_per_wave(win_w, win_h);
     s->order = order; s->win_w = win_w;
-    if (kernel_order_is_half_wave(win_w, win_h)) { s->tap_shift = 3; s->lanes = 32; }
-    else { s->tap_shift = 2; s->lanes = 64; }
+    s->tap_shift = ppw == 4 ? 4 : ppw == 2 ? 3 : 2;
+    s->lanes = 64 / ppw;
     s->rpr = (win_w + (1 << s->tap_shift) - 1) >> s->tap_shift;
     memset(s->lane, 0, sizeof(s->lane));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
@@ -197,14 +204,15 @@ static float wsum_get(wsum* s, int which)
 {
     if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
     {
-        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3 and half_sum2 / half_sum3): whole-wave
-         * shape: fold the upper half-wave onto the lower first; both shapes: fold the upper 16 of the 32 values onto the
-         * lower 16, then an xor butterfly 1,2,4,8 */
+        /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3 and group_sum2 / group_sum1): whole-wave
+         * shape: fold the upper half-wave onto the lower first; whole- and half-wave shapes: fold the upper 16 of the 32 values
+         * onto the lower 16; all shapes: an xor butterfly 1,2,4,8 over the 16 values */
         float a[32], c[16], b[16];
         int off, l;
         if (s->lanes == 64) for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
         else                for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l];
-        for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
+        if (s->lanes == 16) for (l = 0; l < 16; ++l) c[l] = a[l];
+        else                for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
         for (off = 1; off < 16; off <<= 1) {
             for (l = 0; l < 16; ++l) b[l] = c[l] + c[l ^ off];
             memcpy(c, b, sizeof(c));

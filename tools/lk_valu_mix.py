@@ -65,7 +65,7 @@ def cost_of(line):
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "lk_track2_kernelILi15E"
+    want = sys.argv[1] if len(sys.argv) > 1 else "lk_trackg_kernelILi15ELi4E"
     levels = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     iter_levels = float(sys.argv[3]) if len(sys.argv) > 3 else 11.3
     isa = compile_isa()
@@ -100,7 +100,8 @@ def main():
         tot[cls] += w_of_depth.get(cur_depth, 0.0)
     n = sum(tot.values())
     cycles = 2 * tot["fast"] + 4 * tot["std"] + 8 * tot["trans"]
-    out = {"kernel": m.group(1), "source_hash": source_hash(),
+    dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+    out = {"kernel": m.group(1), "kernel_demangled": dem, "source_hash": source_hash(),
            "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0},
            "static_valu": static, "weighted_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
            "weighted_valu_per_wave_total": round(n, 1), "issue_clocks_per_wave": round(cycles, 1),

@@ -1,9 +1,9 @@
-# LK tracker pipe utilisation at the bench's launch shape: rocprofv3 --pmc passes (counters only: no other trace domain;
-# the program itself after "--"), then per-kernel medians.  usage: bash tools/pmc_lk.sh [extra bench.py args]
+# Tracker pipe utilisation at the bench's launch shapes (headline 15x15 kernel + the other-window legs): rocprofv3 --pmc passes
+# (counters only: no other trace domain; the program itself after "--"), then per-kernel medians.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-frontend --no-host-api $@"
+ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-host-api $@"
 run() { n=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_lk_$n -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_lk_$n.log 2>&1 || echo "pmc $n failed"
 }

@@ -11,20 +11,44 @@ tracked files of profiles/<name>/:
 usage: tools/summarize_profiles.py gpurun_out profiles/r01_v4
 """
 import csv
+import glob
+import hashlib
 import json
 import os
 import shutil
 import statistics
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def per_kernel(path, counter):
-    acc = {}
+
+def source_hash(files):
+    """the stamp bench.py compares (bench.kernel_source_hash): a summary is only reported for the kernel sources it was made from"""
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "3dr_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_HASH_FILES = ("pyr_kernels.hip", "warp_kernels.hip", "dr3hip_internal.h")
+LK_HASH_FILES = ("lk_kernels.hip", "dr3hip_internal.h")
+
+
+def per_kernel(path, counter, largest_grid_only=False):
+    """counter values per kernel; largest_grid_only keeps the dispatches of the largest launch shape of each kernel (a kernel that
+    runs at two shapes in one script -- the configs[2] tiles and the KITTI-sized frames -- must not be averaged over both)"""
+    acc, grid = {}, {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            k, g = row["Kernel_Name"], int(row["Grid_Size"])
+            if largest_grid_only:
+                if g > grid.get(k, 0):
+                    grid[k] = g; acc[k] = []
+                if g < grid[k]:
+                    continue
+            acc.setdefault(k, []).append(float(row["Counter_Value"]))
     return acc
 
 
@@ -64,7 +88,7 @@ def main(src, dst):
     json.dump(summary, open(os.path.join(dst, "pmc_fetch_write_summary.json"), "w"), indent=1)
     json.dump({"note": "bytes per launch, median over dispatches; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; "
                        "bench.py --steps 2 --warmup 1 --no-cpu --no-warp (256 frames / 256 pairs x 2000 points per launch)",
-               "kernels": traffic}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+               "source_hash": source_hash(TRAFFIC_HASH_FILES), "kernels": traffic}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     # warp / paste legs (tools/profile_warp.sh): same treatment, separate files
     ks = os.path.join(src, "prof_warp", "warp_kernel_stats.csv")
     if os.path.exists(ks):
@@ -74,7 +98,7 @@ def main(src, dst):
         p = os.path.join(src, sub, stem + "_counter_collection.csv")
         if not os.path.exists(p):
             continue
-        for k, v in per_kernel(p, counter).items():
+        for k, v in per_kernel(p, counter, largest_grid_only=True).items():
             t = wt.setdefault(k, {})
             kb = statistics.median(v)
             if counter == "FETCH_SIZE":
@@ -86,26 +110,53 @@ def main(src, dst):
         if "fetch_bytes" in t and "write_bytes" in t:
             t["hbm_bytes"] = t["fetch_bytes"] + t["write_bytes"]
     if wt:
-        json.dump({"note": "bytes per launch, median over dispatches of tools/warp_quick.py; FETCH_SIZE doubled (gfx950)",
+        json.dump({"note": "bytes per launch of the configs[2] launch shape (the largest dispatch of each kernel in tools/warp_quick.py); "
+                           "FETCH_SIZE doubled (gfx950)", "source_hash": source_hash(TRAFFIC_HASH_FILES),
                    "kernels": wt}, open(os.path.join(dst, "pmc_traffic_warp.json"), "w"), indent=1)
 
-    # per-wave instruction counters of the tracker at the bench's launch shape (tools/profile_all.sh, pmc_lkshape pass)
-    p = os.path.join(src, "pmc_lkshape", "p_counter_collection.csv")
-    if os.path.exists(p):
-        med = {}
-        for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"):
-            for k, v in per_kernel(p, c).items():
-                if "lk_track_kernel<1" in k:
-                    big = [x for x in v] if c != "SQ_WAVES" else v
-                    med[c] = statistics.median(big)
-        if med.get("SQ_WAVES"):
-            w = med["SQ_WAVES"]
-            json.dump({"note": "lk_track_kernel<1, 15> at the bench launch shape (256 pairs x 2000 points), rocprofv3 --pmc, "
-                               "median over the dispatches of bench.py --steps 2 --warmup 1",
-                       "waves": w, "valu_per_wave": med["SQ_INSTS_VALU"] / w, "salu_per_wave": med["SQ_INSTS_SALU"] / w,
-                       "vmem_rd_per_wave": med["SQ_INSTS_VMEM_RD"] / w, "lds_per_wave": med["SQ_INSTS_LDS"] / w,
-                       "branch_per_wave": med["SQ_INSTS_BRANCH"] / w}, open(os.path.join(dst, "pmc_lk.json"), "w"), indent=1)
-    for name in ("bench_default_run.json", "bench_hd_run.json", "pmc_lk_summary.txt"):
+    # pipe utilisation of the tracker kernels (tools/pmc_lk.sh: passes a, b, c of the bench incl. the other-window legs)
+    acc = {}
+    for f in glob.glob(os.path.join(src, "pmc_lk_[abc]", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if "lk_track" not in row["Kernel_Name"]:
+                continue
+            acc.setdefault((row["Kernel_Name"], row["Grid_Size"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    kernels = {}
+    for (name, grid), c in acc.items():
+        m = {k: statistics.median(v) for k, v in c.items()}
+        if not m.get("SQ_WAVES"):
+            continue
+        short = name.split("::")[-1].split("(")[0]
+        w = m["SQ_WAVES"]
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # the counter is summed over the 8 XCDs
+        e = {"grid_size": int(grid), "waves": w, "points_per_wave": (4 if ", 4>" in short else 2) if "lk_trackg" in short else 1,
+             "valu_per_wave": m["SQ_INSTS_VALU"] / w, "salu_per_wave": m["SQ_INSTS_SALU"] / w,
+             "elapsed_clocks": cyc,
+             "active_inst_valu_per_cu_clock": m["SQ_ACTIVE_INST_VALU"] / m["SQ_BUSY_CU_CYCLES"] if m.get("SQ_BUSY_CU_CYCLES") else None,
+             "salu_per_cu_clock": m["SQ_INSTS_SALU"] / 256.0 / cyc,
+             "wait_inst_any_frac": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+             "wait_any_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+             "lds_per_wave": m.get("SQ_INSTS_LDS", 0) / w, "vmem_rd_per_wave": m.get("SQ_INSTS_VMEM_RD", 0) / w,
+             "branch_per_wave": m.get("SQ_INSTS_BRANCH", 0) / w, "smem_per_wave": m.get("SQ_INSTS_SMEM", 0) / w}
+        # keep the bench's own launch shape when a kernel ran at several
+        if short not in kernels or e["waves"] > kernels[short]["waves"]:
+            kernels[short] = e
+    mixf = os.path.join(dst, "valu_mix.json")
+    if kernels:
+        if os.path.exists(mixf):
+            mix = json.load(open(mixf))
+            for short, e in kernels.items():
+                if short.replace(" ", "") in mix.get("kernel_demangled", "").replace(" ", ""):
+                    clk = mix["avg_issue_clocks_per_valu"]
+                    e["valu_issue_busy"] = e["valu_per_wave"] * e["waves"] * clk / (1024.0 * e["elapsed_clocks"])
+                    e["salu_issue_busy"] = e["salu_per_cu_clock"]           # one scalar issue per CU clock
+        json.dump({"note": "tracker kernels at the bench's launch shapes, rocprofv3 --pmc (tools/pmc_lk.sh), medians over dispatches; "
+                           "active_inst_valu_per_cu_clock calibrates to 0.97 for a saturated 4-clock stream and 1.94 for a saturated "
+                           "2-clock stream (tools/pmc_ubench.sh, profiles/r02_lk/pmc_ubench_calibration.txt); valu_issue_busy = "
+                           "VALU instructions x average issue clocks of the kernel's mix (valu_mix.json) / (1024 SIMDs x elapsed clocks)",
+                   "source_hash": source_hash(LK_HASH_FILES), "kernels": kernels}, open(os.path.join(dst, "pmc_lk.json"), "w"), indent=1)
+    for name in ("bench_default_run.json", "bench_hd_run.json", "pmc_lk_summary.txt", "pmc_warpq_summary.txt", "ubench_valu_rate.json",
+                 "pmc_ubench.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, name))
