@@ -582,8 +582,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PPW == 4 &&
     const int itx = 8 * r8;
     const uint32_t loffB = (uint32_t)(ity * lpd + 2 * r8) * 4u;      // byte offset of the lane-item inside a staged region
     const int ntap = ivalid ? win_w - itx : 0;             // taps of this item inside the window, 0 for idle lanes
-    // int16-pair mask of taps (2h, 2h+1): all ones, the low half only, or nothing
-    auto pair_mask = [ntap](int h) -> uint32_t { return ntap >= 2 * h + 2 ? 0xffffffffu : (ntap == 2 * h + 1 ? 0x0000ffffu : 0u); };
+    // int16-pair mask of taps (2h, 2h+1): all ones, the low half only, or nothing.  With a compile-time window and one item per
+    // row the pattern is a constant per h, gated by one lane mask
+    const uint32_t lane_mask = ivalid ? 0xffffffffu : 0u;
+    auto pair_mask = [ntap, lane_mask](int h) -> uint32_t {
+        if (WIN && PPW == 4) return lane_mask & (WIN >= 2 * h + 2 ? 0xffffffffu : (WIN == 2 * h + 1 ? 0x0000ffffu : 0u));
+        return ntap >= 2 * h + 2 ? 0xffffffffu : (ntap == 2 * h + 1 ? 0x0000ffffu : 0u);
+    };
     // staging grid of the group: SR rows x 8 dword columns per round
     const int sc = hl & 7, sr = hl >> 3;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;

@@ -178,12 +178,12 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
 // same physically keeps the tracker on plain addressing everywhere.  The work of one frame is a flat list of wave-tasks
 // over all levels (no idle workgroups): a band task is one of the pad_y rows above / below the image (the reflected
 // source row copied with aligned dword loads, byte gathers only at its two ends); a side task is the left + right
-// border dwords of eight interior rows (32 lanes per row).  Only fill_x columns each side are written (what the tracker can
+// border of eight interior rows.  Side borders are mirror images of the row's own ends, so a lane builds a 16-byte chunk of
+// border from five dwords of the row with four v_perm_b32 (the reversal is a constant byte selector on the left; on the right
+// it depends on w mod 4 only) and stores it with one instruction: 7 lanes per row instead of 17 narrow accesses with byte
+// gathers, which is what this kernel's time was made of.  Only fill_x columns each side are written (what the tracker can
 // read; level 0 reserves more for alignment).  Reads touch the interior only, writes the border (the mixed dword at the right
 // edge rewrites its interior bytes with themselves).  The derivative border is zero from allocation on.
-// Measured (256 KITTI frames, 4 levels): the bands are free next to the launch itself; the side dwords -- 17 narrow
-// accesses per row, 180 000 rows -- cost 30 to 45 us: the next thing to fix (aligned dword pairs + v_perm_b32 reversal
-// instead of byte gathers; 16-byte chunks per lane).
 __device__ __forceinline__ uint32_t border_dword(const uint8_t* __restrict__ srow, int xq, int w)
 {
     if (xq >= 0 && xq + 3 < w) return *reinterpret_cast<const uint32_t*>(srow + xq);
@@ -211,21 +211,56 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
         const int wq = (w + 2 * fill + 3) >> 2;                           // dwords of a band row (from x = -fill)
         for (int q = lane; q < wq; q += 64)
             *reinterpret_cast<uint32_t*>(drow + (q * 4 - fill)) = border_dword(srow, q * 4 - fill, w);
-    } else {
-        const int lq = fill >> 2;                                         // left border dwords of an interior row
-        const int r0 = w >> 2;                                            // first dword (interior numbering) that is not purely interior
-        const int rq = ((w + fill + 3) >> 2) - r0;                        // right border dwords (incl. the mixed one)
-        const int c = lane & 31;
-        if (c >= lq + rq) return;
-        const int xq = c < lq ? c * 4 - fill : (r0 + (c - lq)) * 4;
-        const int y0 = (task - n_band) * 8 + (lane >> 5);
+        return;
+    }
+    const int y = (task - n_band) * 8 + (lane >> 3);
+    const int c = lane & 7;
+    if (y >= h) return;
+    uint8_t* row = img + (long long)y * lv.pitch;
+    const int r0 = w >> 2;                                                // the dword that holds the last interior bytes (mixed if w % 4)
+    const int rq = ((w + fill + 3) >> 2) - r0;                            // right border dwords incl. that one
+    if ((fill & 15) == 0 && w >= fill + 24) {
+        const int nl = fill >> 4;                                         // 16-byte chunks of the left border
+        if (c < nl) {
+            // dst bytes x0 .. x0+15 (x0 = -fill + 16 c) = src[-x0], src[-x0 - 1], ...: dword j of the chunk is bytes
+            // (s + 4, s + 3, s + 2, s + 1) with s = -x0 - 4 j - 4, i.e. [hi.b0, lo.b3, lo.b2, lo.b1] of the aligned pair at s
+            const int s0 = fill - 16 * c - 16;                            // s of j = 3; multiple of 4
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(row + s0);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(d4, d3, 0x01020304u); o.y = __builtin_amdgcn_perm(d3, d2, 0x01020304u);
+            o.z = __builtin_amdgcn_perm(d2, d1, 0x01020304u); o.w = __builtin_amdgcn_perm(d1, d0, 0x01020304u);
+            *reinterpret_cast<uint4*>(row - fill + 16 * c) = o;
+        } else if (c == nl) {
+            *reinterpret_cast<uint32_t*>(row + 4 * r0) = border_dword(row, 4 * r0, w);        // the mixed dword
+        } else {
+            // pure border dwords xq = 4 (r0 + 1 + 4 m + i): bytes src[a], src[a-1], src[a-2], src[a-3], a = 2w - 2 - xq;
+            // a mod 4 = (2w - 2) mod 4 = e for every one of them, so one selector serves the row: byte k of the result is byte
+            // e - k of the aligned dword A = a >> 2, or byte 4 + e - k of dword A - 1
+            const int m = c - nl - 1, first = 1 + 4 * m;                  // index (from r0) of the chunk's first dword
+            if (first < rq) {
+                const int e = (2 * w - 2) & 3;
+                uint32_t sel = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = y0 + 2 * i;
-            if (y < h) {
-                uint8_t* row = img + (long long)y * lv.pitch;
-                *reinterpret_cast<uint32_t*>(row + xq) = border_dword(row, xq, w);
+                for (int k = 0; k < 4; ++k) sel |= (uint32_t)(e - k >= 0 ? 4 + e - k : 4 + e - k) << (8 * k);   // index into {hi = A, lo = A-1}: 4+e-k
+                const int xq = 4 * (r0 + first);
+                const int A = (2 * w - 2 - xq) >> 2;                      // dword of the first result; the chunk needs A-4 .. A
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(row) + (A - 4);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                const uint32_t o0 = __builtin_amdgcn_perm(d4, d3, sel), o1 = __builtin_amdgcn_perm(d3, d2, sel);
+                const uint32_t o2 = __builtin_amdgcn_perm(d2, d1, sel), o3 = __builtin_amdgcn_perm(d1, d0, sel);
+                uint32_t* dq = reinterpret_cast<uint32_t*>(row + xq);
+                const int n = rq - first;                                 // dwords left to write (>= 1)
+                if (n >= 4) { dq[0] = o0; dq[1] = o1; dq[2] = o2; dq[3] = o3; }
+                else { dq[0] = o0; if (n > 1) dq[1] = o1; if (n > 2) dq[2] = o2; }
             }
+        }
+    } else {
+        // narrow levels / odd fill widths: one dword per step with the general reflection
+        const int lq = fill >> 2;
+        for (int k = c; k < lq + rq; k += 8) {
+            const int xq = k < lq ? k * 4 - fill : (r0 + (k - lq)) * 4;
+            *reinterpret_cast<uint32_t*>(row + xq) = border_dword(row, xq, w);
         }
     }
 }
