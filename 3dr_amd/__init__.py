@@ -141,6 +141,7 @@ def _signatures():
         "dr3hip_batch_level_info": ([vp, ip, P(LevelInfo)], ip),
         "dr3hip_batch_upload": ([vp, ip, ip, vp, ip, C.c_size_t], ip),
         "dr3hip_batch_download": ([vp, ip, ip, ip, vp, ip], ip),
+        "dr3hip_batch_pad_level0": ([vp, ip, ip], ip),
         "dr3hip_batch_build": ([vp, ip, ip, ip], ip),
         "dr3hip_batch_track": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, P(LKParams)], ip),
         "dr3hip_batch_align": ([vp, ip, ip, vp, vp, vp, ip, P(AlignParams), vp, vp, vp, vp], ip),

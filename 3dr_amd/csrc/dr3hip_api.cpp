@@ -1012,10 +1012,27 @@ int dr3hip_batch_upload(dr3hip_batch* b, int first, int count, const uint8_t* fr
     dr3hip_ctx* ctx = b->ctx;
     DeviceGuard g(ctx->device);
     const LevelDev& v = b->lv[0];
-    for (int i = 0; i < count; ++i)
-        { const int rc2_ = copy2d_h2d(ctx, v.img + (size_t)(first + i) * v.step, v.pitch, frames + (size_t)i * frame_step, stride,
-                                     b->w, b->h); if (rc2_) return rc2_; }
+    // one linear PCIe copy per frame into the bounce buffer (copy2d_h2d explains why), then the device-side change of pitch
+    // writes the slot's level 0 together with its REFLECT_101 border: whole padded rows, no second pass over the plane
+    const size_t bytes = (size_t)stride * (b->h - 1) + b->w;
+    int rc;
+    if ((rc = stage_reserve(ctx, 7, bytes + 64))) return rc;
+    for (int i = 0; i < count; ++i) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[7].p, frames + (size_t)i * frame_step, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, launch_upload_level0((const uint8_t*)ctx->stage[7].p, (size_t)stride, v, first + i, align_up(b->win_w + 16, 4), ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+int dr3hip_batch_pad_level0(dr3hip_batch* b, int first, int count)
+{
+    if (!b || first < 0 || count < 0 || first + count > b->capacity)
+        return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_pad_level0: slots outside capacity") : DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    DeviceGuard g(ctx->device);
+    for (int s0 = 0; s0 < count; s0 += 32768)
+        HIPCHK(ctx, launch_pad_reflect(&b->lv[0], 1, align_up(b->win_w + 16, 4), first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
     return DR3HIP_OK;
 }
 
@@ -1057,9 +1074,10 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             prof_end(ctx, p0);
         }
     }
-    // the physical REFLECT_101 border of every level (read by the tracker only, never by the pyramid kernels): one launch
-    for (int s0 = 0; s0 < count; s0 += 32768)
-        HIPCHK(ctx, launch_pad_reflect(&b->lv[0], L + 1, align_up(b->win_w + 16, 4), first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
+    // the physical REFLECT_101 border of the levels this pass produced (read by the tracker only, never by the pyramid kernels):
+    // one launch; level 0 got its border when the frame was uploaded (dr3hip_batch_upload)
+    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768)
+        HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, align_up(b->win_w + 16, 4), first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

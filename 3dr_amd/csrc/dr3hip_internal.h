@@ -169,6 +169,7 @@ struct HalfArgs {
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s);
+hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);

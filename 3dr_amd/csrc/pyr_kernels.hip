@@ -265,6 +265,29 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
     }
 }
 
+// A frame enters its slot: level 0 is written WITH its REFLECT_101 border -- whole padded rows, full-line stores -- while it is
+// being written anyway (dr3hip_batch_upload: the host frame has crossed PCIe as one linear copy into a bounce buffer; this kernel
+// is the device-side change of pitch).  pad_reflect_kernel then only serves the levels the pyramid pass produces.
+__global__ __launch_bounds__(256) void upload_level0_kernel(const uint8_t* __restrict__ src, long long spitch, LevelDev lv, int slot, int fill)
+{
+    const int y = (int)blockIdx.y - lv.pad_y;                              // padded rows -pad_y .. h + pad_y - 1
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int wq = (lv.w + 2 * fill + 3) >> 2;
+    if (q >= wq) return;
+    const int xq = q * 4 - fill;
+    const uint8_t* srow = src + (long long)reflect101(y, lv.h) * spitch;
+    uint32_t v;
+    if (xq >= 0 && xq + 3 < lv.w && ((reinterpret_cast<uintptr_t>(srow) + (uintptr_t)xq) & 3) == 0) {
+        v = *reinterpret_cast<const uint32_t*>(srow + xq);
+    } else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, lv.w)] << (8 * k);
+    }
+    uint8_t* img = lv.img + (long long)slot * lv.step;
+    *reinterpret_cast<uint32_t*>(img + (long long)y * lv.pitch + xq) = v;
+}
+
 }  // namespace
 
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s)
@@ -280,6 +303,15 @@ hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int firs
     }
     dim3 block(256), grid(tasks / 4, n_slots);                           // one launch for every padded level
     hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s)
+{
+    const int fill = fill_x < lv.pad_x ? fill_x : lv.pad_x;
+    const int wq = (lv.w + 2 * fill + 3) / 4;
+    dim3 block(256), grid((wq + 255) / 256, lv.h + 2 * lv.pad_y);
+    hipLaunchKernelGGL(upload_level0_kernel, grid, block, 0, s, d_src, (long long)spitch, lv, slot, fill);
     return hipGetLastError();
 }
 

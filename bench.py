@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PRE_ROLL_STEPS = 12          # untimed steady-state pre-roll before the W warm-up steps (about 25 ms of device time)
+PRE_ROLL_STEPS = 32          # untimed steady-state pre-roll before the W warm-up steps (about 40 ms of device time: the
+                             # tracker's launches keep getting faster for that long, 1.25 -> 1.00 ms in profiles/r02_v1's kernel trace)
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (a measured copy rate is reported as hbm_copy_measured_GBps)
 
 KITTI_W, KITTI_H = 1241, 376

@@ -153,6 +153,10 @@ int  dr3hip_batch_level_info(const dr3hip_batch* b, int level, dr3hip_level_info
  * bytes) into slots first..first+count-1 (level 0).  Synchronous. */
 int  dr3hip_batch_upload(dr3hip_batch* b, int first, int count,
                          const uint8_t* frames, int stride, size_t frame_step);
+/* Every level of a slot carries OpenCV's winSize border physically (REFLECT_101 pixels; dr3hip_batch_upload writes level 0's with
+ * the frame, dr3hip_batch_build those of the levels it produces).  A caller that writes level-0 pixels into a slot by other means
+ * (through the device pointers of dr3hip_batch_level_info) calls this before dr3hip_batch_build / _track.  Enqueued on the stream. */
+int  dr3hip_batch_pad_level0(dr3hip_batch* b, int first, int count);
 /* copy one level of one slot back (tests): what = 0 image (u8, w*h), 1 derivative (int16 w*h*2) */
 int  dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void* host, int host_stride);
 

@@ -36,21 +36,47 @@ def test_contract_fields_and_arithmetic():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and c["unit"] == d["unit"]
     assert isinstance(d["warped_mpix_per_sec_1241x376"], float)               # the second half of BASELINE's metric
+    # every roofline fraction in the line is a fraction: a value above 1 means a wrong denominator (round 1's LK figure was)
+    def fracs(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "frac" and v is not None:
+                    assert 0.0 < v <= 1.0, (path, v)
+                fracs(v, path + "/" + k)
+    fracs(d)
+    vi = d["lk_kernel"]["valu_issue"]
+    if vi is not None:                                                        # None when the profile was made for other kernel sources
+        assert vi["frac"] == pytest.approx(vi["achieved"] / vi["peak"], rel=1e-9) and 2.0 <= vi["avg_issue_clocks_per_valu"] <= 8.0
+        assert vi["peak"] == pytest.approx(1024 * 2.4 / vi["avg_issue_clocks_per_valu"], rel=1e-9)
+    # every leg that ran carries its check against the oracle
+    assert d["raster_order_agreement"]["same_path_within_tol"] is True and 0.99 <= d["raster_within_1e-3_frac"] <= 1.0
+    for leg in ("8uc3", "32fc4", "kitti_frames_8uc3", "paste", "stitch"):
+        assert d["warp"][leg]["verified_vs_oracle"] is True, leg
+    for leg in d["lk_other_windows"].values():
+        assert leg["verified_vs_oracle"] is True
+    assert d["sparse_align"]["verified_vs_cpu_statement"] is True
 
 
 def test_live_timing_agrees_with_rocprof_summary_of_the_same_run():
     """profiles/<round>/bench_line_under_rocprof.json is the line bench.py printed INSIDE the rocprofv3 --kernel-trace --stats
-    run whose summary is kernel_stats.csv: the live HIP-event averages and the profiler's averages of that one run agree"""
+    run whose summary is kernel_stats.csv: the live HIP-event averages and the profiler's durations of that one run agree.  The
+    live figures cover the timed launches only, so they are compared with the profiler's mean over exactly those launches
+    (kernel_trace_timed.json, from the same trace); kernel_stats.csv's average also contains the slower pre-roll launches and
+    must not be below it"""
     _, path = _newest()
     here = os.path.dirname(path)
-    line, stats = os.path.join(here, "bench_line_under_rocprof.json"), os.path.join(here, "kernel_stats.csv")
-    if not (os.path.exists(line) and os.path.exists(stats)):
+    line, stats, timed = (os.path.join(here, f) for f in ("bench_line_under_rocprof.json", "kernel_stats.csv", "kernel_trace_timed.json"))
+    if not all(os.path.exists(f) for f in (line, stats, timed)):
         pytest.skip("no rocprof run recorded beside the bench line")
     import csv
     d = json.loads(open(line).read())
+    t = json.load(open(timed))["kernels"]
+    l0 = [v for k, v in t.items() if "pyr_level_kernel<true, true, 0>" in k]
+    lk = [v for k, v in t.items() if d["lk_kernel"]["kernel"] in k]
+    assert l0 and lk and lk[0]["timed_launches"] == d["steps"]
+    # a HIP event pair around a launch also holds the few microseconds between the events and the kernel: 5 % of a 0.12 ms kernel
+    assert l0[0]["mean_ms_timed"] <= d["roofline"]["avg_launch_ms"] <= 1.07 * l0[0]["mean_ms_timed"]
+    assert d["lk_kernel"]["avg_launch_ms"] == pytest.approx(lk[0]["mean_ms_timed"], rel=0.03)
     rows = {r["Name"]: float(r["AverageNs"]) * 1e-6 for r in csv.DictReader(open(stats))}
-    l0 = [v for k, v in rows.items() if "pyr_level_kernel<true, true, 0>" in k]
-    lk = [v for k, v in rows.items() if "lk_track_kernel" in k]
-    assert l0 and lk
-    assert d["roofline"]["avg_launch_ms"] == pytest.approx(l0[0], rel=0.05)
-    assert d["lk_kernel"]["avg_launch_ms"] == pytest.approx(lk[0], rel=0.05)
+    all_lk = [v for k, v in rows.items() if d["lk_kernel"]["kernel"] in k]
+    assert all_lk and all_lk[0] == pytest.approx(lk[0]["mean_ms_all"], rel=1e-3) and all_lk[0] >= 0.98 * lk[0]["mean_ms_timed"]

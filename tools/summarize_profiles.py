@@ -11,6 +11,7 @@ tracked files of profiles/<name>/:
 usage: tools/summarize_profiles.py gpurun_out profiles/r01_v4
 """
 import csv
+import re
 import glob
 import hashlib
 import json
@@ -66,6 +67,26 @@ def main(src, dst):
         lines = [l for l in open(log) if l.startswith("{")]
         if lines:
             open(os.path.join(dst, "bench_line_under_rocprof.json"), "w").write(lines[-1])
+
+    # the rocprofv3 average of a kernel covers every launch of the run, the pre-roll and warm-up ones included, which run a few per
+    # cent slower (the part is still settling); the bench times the LAST `steps` launches.  Record the mean of exactly those from the
+    # same kernel trace, so that the live HIP-event figures can be compared like for like (tests/test_bench_contract.py).
+    kt, bl = os.path.join(src, "prof_r1", "bench_kernel_trace.csv"), os.path.join(dst, "bench_line_under_rocprof.json")
+    if os.path.exists(kt) and os.path.exists(bl):
+        steps = json.loads(open(bl).read())["steps"]
+        per = {}
+        for row in csv.DictReader(open(kt, newline="")):
+            per.setdefault(row["Kernel_Name"], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        timed = {}
+        for k, v in per.items():
+            if "lk_track" in k or "pyr_level_kernel<true, true, 0>" in k:
+                v.sort()
+                last = [d for _, d in v[-steps:]]
+                timed[k] = {"launches_in_run": len(v), "timed_launches": len(last), "mean_ms_timed": sum(last) / len(last) * 1e-6,
+                            "mean_ms_all": sum(d for _, d in v) / len(v) * 1e-6}
+        json.dump({"note": "rocprofv3 --kernel-trace of the bench run whose line is bench_line_under_rocprof.json: mean duration of the last "
+                           "`steps` launches (the timed region) and of all launches (what kernel_stats.csv averages)", "kernels": timed},
+                  open(os.path.join(dst, "kernel_trace_timed.json"), "w"), indent=1)
 
     summary, traffic = {}, {}
     for counter, sub, stem in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "pmc_write", "write")):
@@ -126,7 +147,8 @@ def main(src, dst):
         m = {k: statistics.median(v) for k, v in c.items()}
         if not m.get("SQ_WAVES"):
             continue
-        short = name.split("::")[-1].split("(")[0]
+        mm = re.search(r"(lk_track\w*<[^>]*>)", name)
+        short = mm.group(1) if mm else name
         w = m["SQ_WAVES"]
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # the counter is summed over the 8 XCDs
         e = {"grid_size": int(grid), "waves": w, "points_per_wave": (4 if ", 4>" in short else 2) if "lk_trackg" in short else 1,
@@ -138,18 +160,21 @@ def main(src, dst):
              "wait_any_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
              "lds_per_wave": m.get("SQ_INSTS_LDS", 0) / w, "vmem_rd_per_wave": m.get("SQ_INSTS_VMEM_RD", 0) / w,
              "branch_per_wave": m.get("SQ_INSTS_BRANCH", 0) / w, "smem_per_wave": m.get("SQ_INSTS_SMEM", 0) / w}
-        # keep the bench's own launch shape when a kernel ran at several
-        if short not in kernels or e["waves"] > kernels[short]["waves"]:
+        # keep the bench's own launch shape when a kernel ran at several: the shape with the most dispatches (the timed region and
+        # its pre-roll), the larger one on a tie
+        e["dispatches"] = len(c.get("SQ_WAVES", []))
+        if short not in kernels or (e["dispatches"], e["waves"]) > (kernels[short]["dispatches"], kernels[short]["waves"]):
             kernels[short] = e
-    mixf = os.path.join(dst, "valu_mix.json")
     if kernels:
-        if os.path.exists(mixf):
+        for mixf in glob.glob(os.path.join(dst, "valu_mix*.json")):
             mix = json.load(open(mixf))
             for short, e in kernels.items():
                 if short.replace(" ", "") in mix.get("kernel_demangled", "").replace(" ", ""):
                     clk = mix["avg_issue_clocks_per_valu"]
+                    e["avg_issue_clocks_per_valu"] = clk
                     e["valu_issue_busy"] = e["valu_per_wave"] * e["waves"] * clk / (1024.0 * e["elapsed_clocks"])
                     e["salu_issue_busy"] = e["salu_per_cu_clock"]           # one scalar issue per CU clock
+                    e["clock_ghz"] = None
         json.dump({"note": "tracker kernels at the bench's launch shapes, rocprofv3 --pmc (tools/pmc_lk.sh), medians over dispatches; "
                            "active_inst_valu_per_cu_clock calibrates to 0.97 for a saturated 4-clock stream and 1.94 for a saturated "
                            "2-clock stream (tools/pmc_ubench.sh, profiles/r02_lk/pmc_ubench_calibration.txt); valu_issue_busy = "
