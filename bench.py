@@ -325,6 +325,12 @@ def main(argv=None):
     if args.batch is None:
         args.batch = 64 if args.workload == "hd" else 256
 
+    # The contract is ONE JSON line on stdout.  RCCL and Gloo print banners on file descriptor 1 ("RCCL version : ...", "[Gloo] Rank 0
+    # is connected ..."): keep a private handle on the real stdout for the line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     # torch first: its bundled libamdhip64 and ours share one SONAME, so whichever is loaded first
     # serves both; loading torch's first keeps a single HIP runtime in the process.
     import torch
@@ -537,7 +543,7 @@ def main(argv=None):
             "ref_pyramid_bcast": ref_bcast,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     if leg_hung:                 # a thread is still inside RCCL: no orderly teardown is possible, and the run FAILED
         print("bench.py: the reference-pyramid broadcast leg did not complete (see ref_pyramid_bcast.error)", file=sys.stderr)

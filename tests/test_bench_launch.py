@@ -29,6 +29,7 @@ def test_gpus_2_launches_two_ranks_and_aggregates():
     r, lines = _run(["--gpus", "2"] + COMMON, _env())
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    assert r.stdout.strip() == lines[0], "nothing but that line on stdout (library banners go to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["sequences"] == 2 and d["steps"] == 5 and d["warmup"] == 1
     assert d["data"].startswith("standin") and d["verified_vs_oracle"] is None
