@@ -632,7 +632,8 @@ def align_leg(dist, ctx, dr3, synth, batch, frames, B, intr, sync, have_gpu, ste
                   int(d_n.download((B,), np.int32)[0]) == on and np.array_equal(iters[0][:batch.levels], oi))
     k_ms = ms / max(cnt, 1)
     out = {"pairs_per_launch": B, "features_per_pair": n, "levels": [3, 1], "max_iterations_per_level": 10,
-           "kernel_ms": k_ms, "pairs_per_sec": aggregate_rate(dist, B * steps, el),
+           "kernel_ms": k_ms, "pairs_per_sec_kernel_only": B / (k_ms * 1e-3),
+           "pairs_per_sec_with_prior_upload": aggregate_rate(dist, B * steps, el),
            "patch_pixel_evaluations_per_sec_kernel_only": float(iters.sum()) * n * 16 / (k_ms * 1e-3),
            "mean_iterations_per_pair": float(iters.sum() / B), "mean_measurements": float(d_n.download((B,), np.int32).mean()),
            "verified_vs_cpu_statement": ok, "note": "extension specified by this build: no reference parity exists"}
