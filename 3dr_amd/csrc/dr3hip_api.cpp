@@ -924,7 +924,7 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
     if (w < 4 || h < 4 || capacity < 1 || max_level < 0 || win_w <= 2 || win_h <= 2)
         return fail(ctx, DR3HIP_EINVAL, "batch_create: bad geometry w=%d h=%d win=%dx%d maxLevel=%d capacity=%d", w, h, win_w, win_h, max_level, capacity);
     if (max_level >= DR3HIP_MAX_LEVELS) return fail(ctx, DR3HIP_ERANGE, "batch_create: maxLevel %d >= %d", max_level, DR3HIP_MAX_LEVELS);
-    if (win_w > DR3HIP_MAX_WIN || win_h > DR3HIP_MAX_WIN || ((win_w + 3) / 4) * win_h > 256)
+    if (win_w > DR3HIP_MAX_WIN || win_h > DR3HIP_MAX_WIN)
         return fail(ctx, DR3HIP_ERANGE, "batch_create: window %dx%d exceeds this build's limit (%d)", win_w, win_h, DR3HIP_MAX_WIN);
     if (w <= win_w || h <= win_h)
         return fail(ctx, DR3HIP_ERANGE, "batch_create: image %dx%d must be larger than the window %dx%d", w, h, win_w, win_h);
@@ -1094,14 +1094,6 @@ static int fill_lk_args(dr3hip_batch* b, const dr3hip_lk_params* p, LKArgs& a)
     for (int l = 0; l <= L; ++l) a.lv[l] = b->lv[l];
     a.max_level = L;
     a.win_w = p->win_w; a.win_h = p->win_h;
-    a.rpr = (p->win_w + 3) / 4;
-    a.rpr_magic = (65536 + a.rpr - 1) / a.rpr;
-    a.n_items = a.rpr * p->win_h;
-    // staged J search region (lk_kernels.hip): window + one alignment dword + 4 px margin each side
-    a.rwd = a.rpr + 3;
-    a.rh = p->win_h + 1 + 8;
-    a.lpd = a.rwd | 1;
-    a.cw_shift = a.rwd <= 8 ? 3 : 4;
     // TermCriteria clamping of SparsePyrLKOpticalFlowImpl::calc
     a.max_count = (p->crit_type & DR3HIP_CRIT_COUNT) ? (p->max_iters < 0 ? 0 : p->max_iters > 100 ? 100 : p->max_iters) : 30;
     double eps = (p->crit_type & DR3HIP_CRIT_EPS) ? (p->eps < 0. ? 0. : p->eps > 10. ? 10. : p->eps) : 0.01;

@@ -241,6 +241,21 @@ def lk_valu_issue(lk_ms, waves, kernel):
                     "tools/ubench/valu_rate.hip); *_busy_profiled = issue clocks / elapsed clocks inside the rocprofv3 run at its own clock"}
 
 
+def lk_kernel_of(win_w, win_h):
+    """Name of the tracker instantiation launch_lk_track (3dr_amd/csrc/lk_kernels.hip) picks for a window: <WIN, points per wave,
+    lane-items per lane>; WIN = 0 is the run-time-window form."""
+    n8 = (win_w + 7) // 8 * win_h
+    if win_w <= 16 and win_h <= 16:
+        ppw, ni, fixed = 4, 1, 15
+    elif win_w <= 16 and n8 <= 32:
+        ppw, ni, fixed = 2, 1, -1
+    elif n8 <= 64:
+        ppw, ni, fixed = 2, 2, 21
+    else:
+        ppw, ni, fixed = 1, 2, 30
+    return "lk_trackg_kernel<%d, %d, %d>" % (win_w if win_w == win_h == fixed else 0, ppw, ni)
+
+
 def level_sizes(w, h, levels):
     out = []
     for _ in range(levels):
@@ -492,9 +507,7 @@ def main(argv=None):
         ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
         ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
         traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B)
-        half_wave = WIN <= 16                                          # square windows up to 16x16: four points per wave
-        lk_kernel_name = ("lk_trackg_kernel<%d, 4>" % (WIN if WIN == 15 else 0)) if half_wave else \
-            "lk_track_kernel<%d, %d>" % ((((WIN + 3) // 4) * WIN + 63) // 64, WIN if WIN == 21 else 0)
+        lk_kernel_name = lk_kernel_of(WIN, WIN)
         out = {
             "metric": "tracked_keypoints_per_sec",
             "value": kps,
@@ -644,9 +657,8 @@ def align_leg(dist, ctx, dr3, synth, batch, frames, B, intr, sync, have_gpu, ste
 
 def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
     """The tracker at the parameters the reference's call site really passes (src/initialization.cpp:593-613: 30x30 window,
-    maxLevel 4 -> 3 at this size, 1000 -> 100 iterations, eps 1e-3, USE_INITIAL_FLOW with the identity guess of :578), which
-    runs the generic four-pass kernel, and at BASELINE configs[0] (21x21, 3 levels, ~500 corners), the compile-time two-pass
-    kernel; 128 pairs x 546 grid corners per launch, resident inputs, kernel time from HIP events, pair 0 against the oracle.
+    maxLevel 4 -> 3 at this size, 1000 -> 100 iterations, eps 1e-3, USE_INITIAL_FLOW with the identity guess of :578), one
+    point per wave, and at BASELINE configs[0] (21x21, 3 levels, ~500 corners), two points per wave; 128 pairs x 546 grid corners per launch, resident inputs, kernel time from HIP events, pair 0 against the oracle.
     Untimed extras beside the headline metric."""
     W_, H_, NP = len(frames[0][0]), len(frames[0]), 128
     pts = synth.grid_points(W_, H_, 30)
@@ -654,8 +666,8 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
     P = np.ascontiguousarray(np.broadcast_to(pts[None], (NP, n, 2)), np.float32)
     out = {}
     cases = (("reference_literals_30x30", dict(win=(30, 30), max_level=4, max_iters=1000, eps=1e-3, flags=dr3.LK_USE_INITIAL_FLOW if have_gpu else 4),
-              "lk_track_kernel<4, 0>"),
-             ("configs0_21x21_3_levels", dict(win=(21, 21), max_level=2, max_iters=30, eps=0.01, flags=0), "lk_track_kernel<2, 21>"))
+              lk_kernel_of(30, 30)),
+             ("configs0_21x21_3_levels", dict(win=(21, 21), max_level=2, max_iters=30, eps=0.01, flags=0), lk_kernel_of(21, 21)))
     for name, kw, kernel in cases:
         b = dr3.FrameBatch(ctx, W_, H_, win=kw["win"], max_level=kw["max_level"], capacity=NP + 1)
         for s0 in range(0, NP + 1, 64):

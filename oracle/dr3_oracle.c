@@ -166,14 +166,14 @@ typedef struct {
     float acc[3];
 } wsum;
 
-/* The HIP tracker has three shapes (3dr_amd/csrc/lk_kernels.hip).  Windows up to 16 x 16 (e.g. the bench's 15x15) are tracked by a
- * QUARTER of a wave -- 16 lanes, one window row of up to 16 taps per lane, four points per wave64; the other windows of at most 32
- * lane-items of 8 taps (win_w <= 16, ceil(win_w / 8) * win_h <= 32, e.g. 8x32) by HALF a wave, two points per wave; larger windows
- * by a whole wave with lane-items of 4 taps.  DR3O_ORDER_WAVE64 follows whichever applies. */
+/* The HIP tracker (3dr_amd/csrc/lk_kernels.hip) tracks a point with a GROUP of lanes.  Windows up to 16 x 16 (e.g. the bench's
+ * 15x15): a QUARTER of a wave -- 16 lanes, one window row of up to 16 taps per lane, four points per wave64.  Every other window is
+ * cut into lane-items of 8 taps: at most 64 of them (e.g. 8x32, 21x21) go to HALF a wave, two points per wave; more (e.g. the
+ * reference's 30x30) to a whole wave.  DR3O_ORDER_WAVE64 follows whichever applies. */
 static int kernel_points_per_wave(int win_w, int win_h)
 {
     if (win_w <= 16 && win_h <= 16) return 4;
-    if (win_w <= 16 && ((win_w + 7) / 8) * win_h <= 32) return 2;
+    if (((win_w + 7) / 8) * win_h <= 64) return 2;
     return 1;
 }
 
@@ -181,7 +181,7 @@ static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {
     const int ppw = kernel_points_per_wave(win_w, win_h);
     s->order = order; s->win_w = win_w;
-    s->tap_shift = ppw == 4 ? 4 : ppw == 2 ? 3 : 2;
+    s->tap_shift = ppw == 4 ? 4 : 3;
     s->lanes = 64 / ppw;
     s->rpr = (win_w + (1 << s->tap_shift) - 1) >> s->tap_shift;
     memset(s->lane, 0, sizeof(s->lane));
@@ -189,7 +189,7 @@ static void wsum_init(wsum* s, int order, int win_w, int win_h)
 }
 /* Every term of the three LK window sums is an integer (a product of two fixed-point values, or |diff|).
  * RASTER (OpenCV's scalar path): converted to f32 and added in raster order, each add rounding.
- * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx >> tap_shift); lane = q % lanes (whole-wave shape: pass = q / 64);
+ * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx >> tap_shift); lane = q % lanes;
  * the taps of one lane are summed as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so
  * int32 cannot overflow in the kernel), converted to f32 once, and the lane values go through the f32 tree of wsum_get. */
 static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)

@@ -208,6 +208,26 @@ def test_negative_fourth_bilinear_weight(dr3, O, synth, ctx):
             assert np.array_equal(g_err.view(np.uint32), o_err.view(np.uint32))
 
 
+@pytest.mark.parametrize("win", [(3, 3), (16, 16), (7, 16), (8, 32), (16, 17), (5, 32), (17, 3), (24, 8), (16, 32), (21, 21),
+                                 (32, 16), (25, 21), (17, 32), (30, 30), (31, 32), (32, 32), (9, 29)])
+def test_every_group_shape_bit_exact(dr3, O, synth, ctx, win):
+    """each (points per wave, lane-items per lane) shape of the tracker, at windows on both sides of the shape boundaries and with
+    partial last lane-items, points near all four borders included: bit-exact against the checker's kernel order"""
+    A, B, T = synth.frame_pair(333, 250, motion=dict(tx=2.3, ty=-1.6, rot_deg=0.5, zoom=1.01), seed=11)
+    rng = np.random.default_rng(win[0] * 64 + win[1])
+    pts = np.concatenate([synth.grid_points(333, 250, 24, border=3),
+                          rng.uniform([-2, -2], [335, 252], (40, 2))]).astype(np.float32)
+    for ml, flags in ((3, 0), (1, dr3.LK_GET_MIN_EIGENVALS)):
+        pg, po = _params(dr3, O, win=win, max_level=ml, max_iters=30, eps=0.01, flags=flags)
+        g_xy, g_st, g_err, g_L = ctx.calcOpticalFlowPyrLK(A, B, pts, None, pg)
+        o_xy, o_st, o_err, o_L = O.lk_track(A, B, pts, None, po, order=O.ORDER_WAVE64)
+        assert g_L == o_L
+        assert np.array_equal(g_st, o_st), win
+        assert np.array_equal(g_xy.view(np.uint32), o_xy.view(np.uint32)), win
+        assert np.array_equal(g_err.view(np.uint32), o_err.view(np.uint32)), win
+    assert g_st.sum() > 20
+
+
 def test_flat_image_fails_min_eig(dr3, O, ctx):
     A = np.full((120, 160), 77, np.uint8)
     pts = np.array([[40, 40], [80, 60.5]], np.float32)

@@ -32,8 +32,8 @@ for case in range(n_cases):
     w, h = int(rng.integers(40, int(os.environ.get("FUZZ_MAXW", "700")))), int(rng.integers(36, int(os.environ.get("FUZZ_MAXH", "420"))))
     win = (int(rng.integers(3, 33)), int(rng.integers(3, 33)))
     if rng.random() < 0.25:                        # the compile-time window instantiations
-        win = (15, 15) if rng.random() < 0.5 else (21, 21)
-    if ((win[0] + 3) // 4) * win[1] > 256 or w <= win[0] + 2 or h <= win[1] + 2:
+        win = [(15, 15), (21, 21), (30, 30)][int(rng.integers(0, 3))]
+    if w <= win[0] + 2 or h <= win[1] + 2:
         continue
     ml = int(rng.integers(0, 6)); flags = int(rng.choice([0, 4, 8, 12]))
     mot = dict(tx=rng.uniform(-4, 4), ty=rng.uniform(-3, 3), rot_deg=rng.uniform(-1, 1), zoom=rng.uniform(0.98, 1.03))

@@ -65,7 +65,7 @@ def cost_of(line):
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "lk_trackg_kernelILi15ELi4E"
+    want = sys.argv[1] if len(sys.argv) > 1 else "lk_trackg_kernelILi15ELi4ELi1E"
     levels = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     iter_levels = float(sys.argv[3]) if len(sys.argv) > 3 else 11.3
     isa = compile_isa()

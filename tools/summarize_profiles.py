@@ -151,7 +151,7 @@ def main(src, dst):
         short = mm.group(1) if mm else name
         w = m["SQ_WAVES"]
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # the counter is summed over the 8 XCDs
-        e = {"grid_size": int(grid), "waves": w, "points_per_wave": (4 if ", 4>" in short else 2) if "lk_trackg" in short else 1,
+        e = {"grid_size": int(grid), "waves": w, "points_per_wave": int(re.search(r"<\d+, (\d+)", short).group(1)) if "lk_trackg" in short else 1,
              "valu_per_wave": m["SQ_INSTS_VALU"] / w, "salu_per_wave": m["SQ_INSTS_SALU"] / w,
              "elapsed_clocks": cyc,
              "active_inst_valu_per_cu_clock": m["SQ_ACTIVE_INST_VALU"] / m["SQ_BUSY_CU_CYCLES"] if m.get("SQ_BUSY_CU_CYCLES") else None,
