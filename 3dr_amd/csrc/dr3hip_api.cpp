@@ -948,13 +948,14 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
         v.dpitch = align_up(4 * (lw + 2 * v.pad_x) + 16, 128);
         const int rows = lh + 2 * v.pad_y;
         // the kernels address a plane with 31-bit byte offsets
-        if ((long long)v.dpitch * rows > 0x7fffff00ll) {
+        if ((long long)v.dpitch * (rows + 17) > 0x7fffff00ll) {
             dr3hip_batch_destroy(b);
             return fail(ctx, DR3HIP_ERANGE, "batch_create: level %d plane of %d x %d exceeds the 2 GiB a plane may span", l, lw, lh);
         }
         v.step = align_up((long long)v.pitch * rows, 256ll);
         v.dstep = align_up((long long)v.dpitch * rows, 256ll);
-        const size_t ib = (size_t)v.step * capacity + 256, db = (size_t)v.dstep * capacity + 256;
+        // slack: the tracker's run-time-window forms load (and mask) up to 16 rows below a window that touches the bottom border
+        const size_t ib = (size_t)v.step * capacity + 256 + (size_t)17 * v.pitch, db = (size_t)v.dstep * capacity + 256 + (size_t)17 * v.dpitch;
         void *pi = nullptr, *pd = nullptr;
         if (hipMalloc(&pi, ib) != hipSuccess || hipMalloc(&pd, db) != hipSuccess) {
             if (pi) (void)hipFree(pi);

@@ -147,7 +147,7 @@ __device__ __forceinline__ float group_sum1(float c)
 
 // wave-uniform global base + unsigned 32-bit lane offset: selects the saddr form of global_load
 typedef const __attribute__((address_space(1))) uint8_t* gbase_t;
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <class T>
 __device__ __forceinline__ T ldg(gbase_t base, uint32_t off)
@@ -173,6 +173,9 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef LKG_WAVES
 #define LKG_WAVES 4
 #endif
+#ifndef LKG_RB
+#define LKG_RB 9            // window rows whose LDS reads are issued together in an iteration
+#endif
 #ifndef LKG_WAVES_NI2
 #define LKG_WAVES_NI2 4
 #endif
@@ -189,11 +192,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     constexpr int LANES = 64 / PPW;               // lanes per point
-    constexpr int NT = PPW == 4 ? 16 : 8;         // taps per lane-item
-    constexpr int ND = NT / 4 + 1;                // aligned dwords of an image row a lane-item reads
-    constexpr int COLS = NI == 1 ? 8 : 16;        // dword columns of the staging grid (>= the region's width)
+    constexpr int NT = PPW == 4 ? 16 : 8;         // taps (consecutive window rows of one column) per lane-item
+    constexpr int COLS = PPW == 4 ? 8 : 16;       // dword columns of the staging grid (>= the region's width)
     constexpr int SR = LANES / COLS;              // rows a group stages per round
-    static_assert(PPW != 4 || NI == 1, "a quarter wave holds one 16-tap row per lane");
+    static_assert(PPW != 4 || NI == 1, "a quarter wave holds one window column per lane");
 
     const int lane = threadIdx.x, hl = lane & (LANES - 1), grp = lane / LANES;
     const int pair = blockIdx.y;
@@ -208,42 +210,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
-    const int rpr = PPW == 4 ? 1 : (win_w + 7) >> 3;       // lane-items per window row
-    const int rwd = PPW == 4 ? (win_w > 8 ? 7 : 5) : 2 * rpr + 3, rh = win_h + 9, lpd = rwd;      // staged J region: dwords per row (odd), rows
-    const int rhs = (rh + SR - 1) / SR * SR;               // LDS rows per slice: staging runs in rounds of SR rows
-    const int n_items = rpr * win_h;
+    const int nblk = PPW == 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
+    const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd)
+    // LDS rows per group: staging runs in rounds of SR rows; the run-time forms also read (and mask) the rows of the taps below the window
+    const int rhs = ((WIN ? rh : PPW == 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     uint32_t* __restrict__ lds = lds_all + grp * (rhs * lpd);
 
-    // lane-item geometry: the lane owns the items hl, hl + LANES, ...; slots beyond the last item shadow item 0 with all-zero masks
+    // lane-item geometry: item q = blk * win_w + c covers the taps (8 blk .. 8 blk + 7, c) -- windows up to 16 x 16: the whole column c --
+    // and the lane owns the items hl, hl + LANES, ...; slots beyond the last item shadow item 0 with all-zero masks
     int itx[NI], ity[NI], ntap[NI];
-    uint32_t loffB[NI], lane_mask[NI];                     // loffB: byte offset of the lane-item inside a staged region
+    uint32_t loffB[NI];                                    // byte offset of the lane-item's first row inside a staged region
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int q = hl + i * LANES;
-        const bool ivalid = q < n_items;
-        ity[i] = ivalid ? div_rpr(q, rpr) : 0;
-        const int r8 = ivalid ? q - ity[i] * rpr : 0;
-        itx[i] = 8 * r8;
-        loffB[i] = (uint32_t)(ity[i] * lpd + 2 * r8) * 4u;
-        ntap[i] = ivalid ? win_w - itx[i] : 0;             // taps of this item inside the window, 0 for idle slots
-        lane_mask[i] = ivalid ? 0xffffffffu : 0u;
+        const bool ivalid = q < win_w * nblk;
+        const int blk = (PPW == 4 || !ivalid) ? 0 : (q >= win_w) + (q >= 2 * win_w) + (q >= 3 * win_w);
+        itx[i] = ivalid ? q - blk * win_w : 0;
+        ity[i] = 8 * blk;
+        loffB[i] = (uint32_t)(ity[i] * lpd) * 4u;
+        ntap[i] = ivalid ? win_h - ity[i] : 0;             // taps of this item inside the window (>= NT: all), 0 for idle slots
     }
     // int16-pair mask of taps (2h, 2h+1) of item i: all ones, the low half only, or nothing.  With a compile-time window and one
-    // item per row the pattern is a constant per h, gated by one lane mask
-    auto pair_mask = [&ntap, &lane_mask](int i, int h) -> uint32_t {
-        if (WIN && PPW == 4) return lane_mask[i] & (WIN >= 2 * h + 2 ? 0xffffffffu : (WIN == 2 * h + 1 ? 0x0000ffffu : 0u));
+    // item per column the pattern is a constant per h, and the idle lanes are removed from the lane sums instead (lane_mask)
+    constexpr bool LANE_MASKED = WIN && PPW == 4;
+    const int lane_mask = ntap[0] ? -1 : 0;
+    auto pair_mask = [&ntap](int i, int h) -> uint32_t {
+        if (LANE_MASKED) return WIN >= 2 * h + 2 ? 0xffffffffu : (WIN == 2 * h + 1 ? 0x0000ffffu : 0u);
         return ntap[i] >= 2 * h + 2 ? 0xffffffffu : (ntap[i] == 2 * h + 1 ? 0x0000ffffu : 0u);
     };
+    // a quarter wave with a compile-time window: the taps below the window are not computed at all
+    auto tap_live = [](int k) -> bool { return !(WIN && PPW == 4) || k < WIN; };
     // staging grid of the group: SR rows x COLS dword columns per round
     const int sc = hl & (COLS - 1), sr = hl / COLS;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;
 
     int   status = 1;
     float err = 0.f;
-    int Ib[NI][NT];
-    uint32_t Ix[NI][NT / 2], Iy[NI][NT / 2];
 
     for (int level = a.max_level; level >= 0; --level) {
         const LevelDev& L = a.lv[level];
@@ -305,56 +309,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
         }
 
         // ---- template patch + structure tensor ----------------------------------------------------
+        // Row r of a lane-item: the image byte pair (c, c + 1) and the derivative dword pair of the same columns, one 8-byte load
+        // each; the 16 lanes of a column group read adjacent addresses.  Tap r blends rows r and r + 1: every row is permuted once.
+        int Ib[NI][NT];                              // per tap: the dot accumulator BILIN_ROUND - (I << 9)
+        uint32_t Ix[NI][NT / 2], Iy[NI][NT / 2];     // gradients as int16 pairs of taps (2h, 2h + 1)
+        // Every lane computes it -- a point outside the level (act false) reads the window at the origin instead and its sums are
+        // dropped -- so that the patch registers are defined afresh on every level and nothing is carried around the level loop.
         int s11 = 0, s12 = 0, s22 = 0;
-        if (act) {
+        {
             const Weights W = make_weights(px - fpx, py - fpy);
-            const uint32_t o = (uint32_t)(ipx + pad_x) & 3u;          // itx is a multiple of 8: one byte phase for all items
-            const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
+            const int ipxs = act ? ipx : 0, ipys = act ? ipy : 0;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-            const int xp = ipx + pad_x + itx[i], yp = ipy + pad_y + ity[i];
-            const uint32_t offI = __umul24((unsigned)yp, (unsigned)pitch) + ((unsigned)xp & ~3u);
-            const uint32_t offD = __umul24((unsigned)yp, (unsigned)dpitch) + 4u * (unsigned)xp;
-            uint32_t ra[ND], rb[ND];             // image rows y, y+1 as aligned dwords
-            uint32_t d0[NT + 1], d1[NT + 1];     // packed (Ix | Iy<<16) of rows y, y+1, columns x .. x+NT
-            if (PPW == 4) {
-                const u32x4 a4 = ldg<u32x4>(Ibase, offI), b4 = ldg<u32x4>(Ibase, offI + (unsigned)pitch);
-                ra[0] = a4.x; ra[1] = a4.y; ra[2] = a4.z; ra[3] = a4.w; ra[ND - 1] = ldg<uint32_t>(Ibase, offI + 16u);
-                rb[0] = b4.x; rb[1] = b4.y; rb[2] = b4.z; rb[3] = b4.w; rb[ND - 1] = ldg<uint32_t>(Ibase, offI + (unsigned)pitch + 16u);
-            } else {
-                const u32x3 a3 = ldg<u32x3>(Ibase, offI), b3 = ldg<u32x3>(Ibase, offI + (unsigned)pitch);
-                ra[0] = a3.x; ra[1] = a3.y; ra[2] = a3.z; rb[0] = b3.x; rb[1] = b3.y; rb[2] = b3.z;
-            }
-#pragma unroll
-            for (int q = 0; q < NT / 4; ++q) {
-                const u32x4 u = ldg<u32x4>(Dbase, offD + 16u * q), v = ldg<u32x4>(Dbase, offD + (unsigned)dpitch + 16u * q);
-                d0[4 * q] = u.x; d0[4 * q + 1] = u.y; d0[4 * q + 2] = u.z; d0[4 * q + 3] = u.w;
-                d1[4 * q] = v.x; d1[4 * q + 1] = v.y; d1[4 * q + 2] = v.z; d1[4 * q + 3] = v.w;
-            }
-            d0[NT] = ldg<uint32_t>(Dbase, offD + 4u * NT);
-            d1[NT] = ldg<uint32_t>(Dbase, offD + (unsigned)dpitch + 4u * NT);
-            // every tap is computed; taps beyond the window's last column (and idle lanes) get zero gradients through the
-            // pair masks, which removes them from every sum
-#pragma unroll
-            for (int h = 0; h < NT / 2; ++h) {
+                const int xp = ipxs + pad_x + itx[i], yp = ipys + pad_y + ity[i];
+                const uint32_t selI = 0x0c010c00u + ((uint32_t)xp & 3u) * 0x00010001u;
+                const uint32_t offI = __umul24((unsigned)yp, (unsigned)pitch) + ((unsigned)xp & ~3u);
+                const uint32_t offD = __umul24((unsigned)yp, (unsigned)dpitch) + 4u * (unsigned)xp;
+                uint32_t Pp = 0, Xp = 0, Yp = 0;
                 int gx[2], gy[2];
+                gbase_t rowI = Ibase, rowD = Dbase;          // wave-uniform row bases, advanced on the scalar unit
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int k = 2 * h + t;
-                    const uint32_t sel = (k & 3) == 0 ? sel0 : (k & 3) == 1 ? sel1 : (k & 3) == 2 ? sel2 : sel3;
-                    Ib[i][k] = BILIN_ROUND - (bilin_u8(rows_of<ND>(ra, rb, k >> 2), sel, W, BILIN_ROUND) << (W_BITS - 5));
-                    gx[t] = bilin_s16<0x05040100u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
-                    gy[t] = bilin_s16<0x07060302u>(d0[k], d0[k + 1], d1[k], d1[k + 1], W);
+                for (int r = 0; r <= NT; ++r) {
+                    uint32_t P = 0, X = 0, Y = 0;
+                    if (tap_live(r - 1) || tap_live(r)) {
+                        const u32x2 im = ldg<u32x2>(rowI, offI), dd = ldg<u32x2>(rowD, offD);
+                        rowI += pitch; rowD += dpitch;
+                        P = __builtin_amdgcn_perm(im.y, im.x, selI);
+                        X = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
+                        Y = __builtin_amdgcn_perm(dd.y, dd.x, 0x07060302u);
+                    }
+                    if (r > 0) {
+                        const int k = r - 1;
+                        if (tap_live(k)) {
+                            Ib[i][k] = BILIN_ROUND - ((dot_s16(P, W.w23, dot_s16(Pp, W.w01, BILIN_ROUND)) >> (W_BITS - 5)) << (W_BITS - 5));
+                            gx[k & 1] = dot_s16(X, W.w23, dot_s16(Xp, W.w01, 1 << (W_BITS - 1))) >> W_BITS;
+                            gy[k & 1] = dot_s16(Y, W.w23, dot_s16(Yp, W.w01, 1 << (W_BITS - 1))) >> W_BITS;
+                        } else {
+                            Ib[i][k] = 0; gx[k & 1] = 0; gy[k & 1] = 0;
+                        }
+                        if (k & 1) {
+                            // taps below the window's last row (and idle slots) get zero gradients through the pair masks, which
+                            // removes them from every sum
+                            const uint32_t mkh = pair_mask(i, k >> 1);
+                            const uint32_t x2 = pack_s16(gx[0], gx[1]) & mkh, y2 = pack_s16(gy[0], gy[1]) & mkh;
+                            Ix[i][k >> 1] = x2; Iy[i][k >> 1] = y2;
+                            s11 = dot_s16(x2, x2, s11);
+                            s12 = dot_s16(x2, y2, s12);
+                            s22 = dot_s16(y2, y2, s22);
+                        }
+                    }
+                    Pp = P; Xp = X; Yp = Y;
                 }
-                const uint32_t mkh = pair_mask(i, h);
-                const uint32_t x2 = pack_s16(gx[0], gx[1]) & mkh, y2 = pack_s16(gy[0], gy[1]) & mkh;
-                Ix[i][h] = x2; Iy[i][h] = y2;
-                s11 = dot_s16(x2, x2, s11);
-                s12 = dot_s16(x2, y2, s12);
-                s22 = dot_s16(y2, y2, s22);
-            }
             }
         }
+        if (LANE_MASKED) { s11 &= lane_mask; s12 &= lane_mask; s22 &= lane_mask; }
         float A11, A12, A22;
         group_sum2<PPW>((float)s11, (float)s12, A11, A12);
         A22 = group_sum1<PPW>((float)s22);
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
             int s1 = 0, s2 = 0;
             if (act) {
                 it_count = j + 1;
-                uint32_t dxb = (uint32_t)((inx & ~3) - rx0), dyr = (uint32_t)(iny - ry0);     // byte column / row inside the region
+                uint32_t dxb = (uint32_t)((inx & ~3) - rx0), dyr = (uint32_t)(iny - ry0);     // aligned byte column / row inside the region
                 if (dxb > 8u || dyr > 8u) {
                     // the iterate left the staged region (margin RM px): stage it again around the iterate
                     rx0 = (inx - RM) & ~3;
@@ -401,25 +409,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
                     dxb = (uint32_t)((inx & ~3) - rx0); dyr = (uint32_t)(iny - ry0);
                 }
                 const Weights W = make_weights(cx - fcx, cy - fcy);
-                const uint32_t o = (uint32_t)inx & 3u;
-                const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
-                const uint32_t base = __umul24(dyr, (unsigned)(4 * lpd)) + dxb;
+                const uint32_t base = __umul24(dyr, (unsigned)(4 * lpd));
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (base + loffB[i]));
-                    uint32_t ra[ND], rb[ND];
+                    const uint32_t t = (uint32_t)(inx - rx0) + (uint32_t)itx[i];          // byte column of the item inside the region
+                    const uint32_t sel = 0x0c010c00u + (t & 3u) * 0x00010001u;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (base + loffB[i] + (t & ~3u)));
+                    uint32_t Pp = 0;
+                    int m[2];
+                    uint32_t lo[NT + 1], hi[NT + 1];
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) { ra[q] = p[q]; rb[q] = p[lpd + q]; }
+                    for (int r = 0; r <= NT; ++r) {
+                        if (r % LKG_RB == 0) {
+                            // the LDS reads of the next LKG_RB rows go out together, ahead of the arithmetic on them
 #pragma unroll
-                    for (int h = 0; h < NT / 2; ++h) {
-                        const Rows r = rows_of<ND>(ra, rb, h >> 1);
-                        const uint32_t m = (h & 1) ? pack_s16(bilin_u8(r, sel2, W, Ib[i][2 * h]), bilin_u8(r, sel3, W, Ib[i][2 * h + 1]))
-                                                   : pack_s16(bilin_u8(r, sel0, W, Ib[i][2 * h]), bilin_u8(r, sel1, W, Ib[i][2 * h + 1]));
-                        s1 = dot_s16(m, Ix[i][h], s1);
-                        s2 = dot_s16(m, Iy[i][h], s2);
+                            for (int q = r; q < r + LKG_RB && q <= NT; ++q)
+                                if (tap_live(q - 1) || tap_live(q)) { lo[q] = p[q * lpd]; hi[q] = p[q * lpd + 1]; }
+                            asm volatile("" : "+v"(lo[r]));
+                        }
+                        uint32_t P = 0;
+                        if (tap_live(r - 1) || tap_live(r)) P = __builtin_amdgcn_perm(hi[r], lo[r], sel);
+                        if (r > 0) {
+                            const int k = r - 1;
+                            m[k & 1] = tap_live(k) ? dot_s16(P, W.w23, dot_s16(Pp, W.w01, Ib[i][k])) >> (W_BITS - 5) : 0;
+                            if (k & 1) {
+                                const uint32_t mm = pack_s16(m[0], m[1]);
+                                s1 = dot_s16(mm, Ix[i][k >> 1], s1);
+                                s2 = dot_s16(mm, Iy[i][k >> 1], s2);
+                            }
+                        }
+                        Pp = P;
                     }
                 }
             }
+            if (LANE_MASKED) { s1 &= lane_mask; s2 &= lane_mask; }
             float b1, b2;
             group_sum2<PPW>((float)s1, (float)s2, b1, b2);
             if (act) {
@@ -460,25 +483,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
                     dxb = (uint32_t)((inx & ~3) - rx0); dyr = (uint32_t)(iny - ry0);
                 }
                 const Weights W = make_weights(fx - ffx, fy - ffy);
-                const uint32_t o = (uint32_t)inx & 3u;
-                const uint32_t sel0 = 0x0c010c00u + o * 0x00010001u, sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u, sel3 = sel0 + 0x00030003u;
-                const uint32_t base = __umul24(dyr, (unsigned)(4 * lpd)) + dxb;
+                const uint32_t base = __umul24(dyr, (unsigned)(4 * lpd));
                 // sum of |mismatch| over the taps inside the window: |d| <= 2^13 packed in int16 pairs, dotted with the pair
                 // masks reduced to ones (exact integer sum of at most 16 taps)
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (base + loffB[i]));
-                    uint32_t ra[ND], rb[ND];
+                    const uint32_t t = (uint32_t)(inx - rx0) + (uint32_t)itx[i];
+                    const uint32_t sel = 0x0c010c00u + (t & 3u) * 0x00010001u;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(lds) + (base + loffB[i] + (t & ~3u)));
+                    uint32_t Pp = 0;
+                    int m[2];
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) { ra[q] = p[q]; rb[q] = p[lpd + q]; }
-#pragma unroll
-                    for (int h = 0; h < NT / 2; ++h) {
-                        const Rows r = rows_of<ND>(ra, rb, h >> 1);
-                        const int da = bilin_u8(r, (h & 1) ? sel2 : sel0, W, Ib[i][2 * h]), db = bilin_u8(r, (h & 1) ? sel3 : sel1, W, Ib[i][2 * h + 1]);
-                        se = dot_s16(pack_s16(da < 0 ? -da : da, db < 0 ? -db : db), pair_mask(i, h) & 0x00010001u, se);
+                    for (int r = 0; r <= NT; ++r) {
+                        uint32_t P = 0;
+                        if (tap_live(r - 1) || tap_live(r)) P = __builtin_amdgcn_perm(p[r * lpd + 1], p[r * lpd], sel);
+                        if (r > 0) {
+                            const int k = r - 1;
+                            const int d = tap_live(k) ? dot_s16(P, W.w23, dot_s16(Pp, W.w01, Ib[i][k])) >> (W_BITS - 5) : 0;
+                            m[k & 1] = d < 0 ? -d : d;
+                            if (k & 1) se = dot_s16(pack_s16(m[0], m[1]), pair_mask(i, k >> 1) & 0x00010001u, se);
+                        }
+                        Pp = P;
                     }
                 }
             }
+            if (LANE_MASKED) se &= lane_mask;
             const float tot = group_sum1<PPW>((float)se);
             if (res) err = tot * 1.f / (float)(32 * win_w * win_h);
         }
@@ -498,9 +527,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
 // lane-items per lane ni
 static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
 {
-    const int n8 = ((win_w + 7) / 8) * win_h;
+    const int n8 = win_w * ((win_h + 7) / 8);
     if (win_w <= 16 && win_h <= 16) { ppw = 4; ni = 1; }
-    else if (win_w <= 16 && n8 <= 32) { ppw = 2; ni = 1; }
+    else if (n8 <= 32) { ppw = 2; ni = 1; }
     else if (n8 <= 64) { ppw = 2; ni = 2; }
     else { ppw = 1; ni = 2; }
 }
@@ -511,10 +540,11 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
     if (a.win_w < 3 || a.win_h < 3 || a.win_w > 32 || a.win_h > 32) return hipErrorInvalidValue;
     int ppw, ni;
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
-    const int rpr = (a.win_w + 7) / 8, sr = 64 / ppw / (ni == 1 ? 8 : 16);
-    const int rwd = ppw == 4 ? (a.win_w > 8 ? 7 : 5) : 2 * rpr + 3, rhs = (a.win_h + 9 + sr - 1) / sr * sr;
+    const int sr = 64 / ppw / (ppw == 4 ? 8 : 16), lpd = ((a.win_w + 15) / 4) | 1;
+    const bool fixed = a.win_w == a.win_h && (a.win_w == 15 || a.win_w == 21 || a.win_w == 30);
+    const int rhs = ((fixed ? a.win_h + 9 : ppw == 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;
     dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
-    const size_t shmem = (size_t)ppw * rhs * rwd * sizeof(uint32_t);
+    const size_t shmem = (size_t)ppw * rhs * lpd * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
     if (ppw == 4) {
         if (sq == 15) hipLaunchKernelGGL((lk_trackg_kernel<15, 4, 1>), grid, block, shmem, s, a);

@@ -244,10 +244,10 @@ def lk_valu_issue(lk_ms, waves, kernel):
 def lk_kernel_of(win_w, win_h):
     """Name of the tracker instantiation launch_lk_track (3dr_amd/csrc/lk_kernels.hip) picks for a window: <WIN, points per wave,
     lane-items per lane>; WIN = 0 is the run-time-window form."""
-    n8 = (win_w + 7) // 8 * win_h
+    n8 = win_w * ((win_h + 7) // 8)
     if win_w <= 16 and win_h <= 16:
         ppw, ni, fixed = 4, 1, 15
-    elif win_w <= 16 and n8 <= 32:
+    elif n8 <= 32:
         ppw, ni, fixed = 2, 1, -1
     elif n8 <= 64:
         ppw, ni, fixed = 2, 2, 21

@@ -160,20 +160,21 @@ static inline int der_at(const lvl_deriv* D, int x, int y, int c)
 /* Window-sum accumulator that can emulate either summation order. */
 typedef struct {
     int   order;
-    int   win_w, rpr;             /* lane-items per window row in the kernel's order */
-    int   tap_shift, lanes;       /* kernel's order: log2(taps per lane-item) and lanes per point (64, or 32 = half a wave) */
+    int   win_w;
+    int   blk_shift, lanes;       /* kernel's order: log2(rows per lane-item) and lanes per point (64, 32 = half or 16 = a quarter of a wave) */
     long long lane[3][64];        /* up to three simultaneous sums: the lane-local part is an exact integer sum */
     float acc[3];
 } wsum;
 
-/* The HIP tracker (3dr_amd/csrc/lk_kernels.hip) tracks a point with a GROUP of lanes.  Windows up to 16 x 16 (e.g. the bench's
- * 15x15): a QUARTER of a wave -- 16 lanes, one window row of up to 16 taps per lane, four points per wave64.  Every other window is
- * cut into lane-items of 8 taps: at most 64 of them (e.g. 8x32, 21x21) go to HALF a wave, two points per wave; more (e.g. the
- * reference's 30x30) to a whole wave.  DR3O_ORDER_WAVE64 follows whichever applies. */
+/* The HIP tracker (3dr_amd/csrc/lk_kernels.hip) tracks a point with a GROUP of lanes, and a lane owns taps of ONE window column.
+ * Windows up to 16 x 16 (e.g. the bench's 15x15): a QUARTER of a wave -- 16 lanes, lane = column, four points per wave64.  Every
+ * other window is cut into lane-items of 8 consecutive rows of a column, item q = (ty / 8) * win_w + tx on lane q % lanes: at most
+ * 64 items (e.g. 8x32, 21x21) go to HALF a wave, two points per wave; more (e.g. the reference's 30x30) to a whole wave.
+ * DR3O_ORDER_WAVE64 follows whichever applies. */
 static int kernel_points_per_wave(int win_w, int win_h)
 {
     if (win_w <= 16 && win_h <= 16) return 4;
-    if (((win_w + 7) / 8) * win_h <= 64) return 2;
+    if (win_w * ((win_h + 7) / 8) <= 64) return 2;
     return 1;
 }
 
@@ -181,22 +182,21 @@ static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {
     const int ppw = kernel_points_per_wave(win_w, win_h);
     s->order = order; s->win_w = win_w;
-    s->tap_shift = ppw == 4 ? 4 : 3;
+    s->blk_shift = ppw == 4 ? 4 : 3;
     s->lanes = 64 / ppw;
-    s->rpr = (win_w + (1 << s->tap_shift) - 1) >> s->tap_shift;
     memset(s->lane, 0, sizeof(s->lane));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
 }
 /* Every term of the three LK window sums is an integer (a product of two fixed-point values, or |diff|).
  * RASTER (OpenCV's scalar path): converted to f32 and added in raster order, each add rounding.
- * WAVE64 (the HIP kernel): lane-item q = ty*rpr + (tx >> tap_shift); lane = q % lanes;
+ * WAVE64 (the HIP kernel): lane-item q = (ty >> blk_shift) * win_w + tx; lane = q % lanes;
  * the taps of one lane are summed as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so
  * int32 cannot overflow in the kernel), converted to f32 once, and the lane values go through the f32 tree of wsum_get. */
 static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)
 {
     if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += (float)v; return; }
     {
-        const int q = ty * s->rpr + (tx >> s->tap_shift);
+        const int q = (ty >> s->blk_shift) * s->win_w + tx;
         s->lane[which][q & (s->lanes - 1)] += v;
     }
 }

@@ -44,10 +44,11 @@ extern "C" {
 
 /* float summation order of the window sums (A11,A12,A22,b1,b2,err) */
 #define DR3O_ORDER_RASTER   0  /* OpenCV's scalar path: y outer, x inner, one f32 accumulator */
-#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order.  Windows up to 16x16: 16 lanes (a quarter of a wave64 per point), one window row per
-                                 * lane; other windows: lane-items of 8 taps, item q on lane q % lanes, lanes = 32 (upper 16 folded onto the
-                                 * lower 16) for <= 64 items, else 64 (upper half-wave folded onto the lower first).  Lane partial sums are
-                                 * exact integers converted to f32 once; then all: xor butterfly 1,2,4,8 */
+#define DR3O_ORDER_WAVE64   1  /* the HIP kernel's order.  A lane sums taps of one window column.  Windows up to 16x16: 16 lanes (a quarter of a
+                                 * wave64 per point), lane = column; other windows: lane-items of 8 consecutive rows of a column, item
+                                 * q = (ty / 8) * win_w + tx on lane q % lanes, lanes = 32 (upper 16 folded onto the lower 16) for <= 64 items,
+                                 * else 64 (upper half-wave folded onto the lower first).  Lane partial sums are exact integers converted to
+                                 * f32 once; then all: xor butterfly 1,2,4,8 */
 
 /* half-sample rounding / addressing modes (src/utils.cpp:382-419) */
 #define DR3O_HALF_TRUNC      0 /* row-aligned, (a+b+c+d)/4 truncating  (scalar :411, NEON :353-372) */
