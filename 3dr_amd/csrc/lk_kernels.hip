@@ -2,41 +2,45 @@
 // cv::calcOpticalFlowPyrLK as called at reference src/initialization.cpp:608-613
 // (LKTrackerInvoker).
 //
-// Mapping: ONE wave64 per (frame pair, point), one wave per workgroup; all pyramid levels run
-// coarse -> fine inside the wave, the running estimate never leaves registers.  The window is cut
-// into lane-items: item q = ty * rpr + r covers the 4 taps (ty, 4r .. 4r+3); lane = q % 64,
-// pass = q / 64 (NPASS passes, template parameter so the patch lives in statically indexed VGPRs).
-// Per level the wave
-//   1. stages the J search region (window + RM px margin, REFLECT_101 already applied) from
-//      global memory into its private LDS slice with aligned dword loads -- ONE global round trip
-//      per level instead of one per Gauss-Newton iteration;
-//   2. extracts its taps of the template patch (I, Ix, Iy: 14-bit fixed-point bilinear, integer
-//      exact) once and keeps them in registers;
-//   3. iterates out of LDS: two ds_read2_b32 per lane-item, v_perm_b32 + v_dot2_i32_i16 for the
-//      bilinear J taps (the template value rides in the dot's accumulator, so the dot yields the
-//      mismatch directly), mismatches packed in int16 pairs and multiplied onto the packed
-//      gradients with v_dot2_i32_i16 again: 6.5 VALU per tap;
-//   4. reduces the two sums across the wave with v_permlane32_swap + v_permlane16_swap + DPP adds (no
-//      LDS), solves the 2x2 system redundantly in every lane and tests the wave-uniform exit conditions.
-// Scalar registers are the scarce resource (96 at the 8 waves per SIMD the one-pass kernel is pinned to):
-// the 15x15 and 21x21 windows have compile-time instantiations (WIN), and the one-pass kernel drops
-// out-of-window taps and idle lanes through zero masks on the packed gradients instead of branches whose
-// exec masks would occupy SGPR pairs for the kernel's lifetime.
-// If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged
-// around it, so results never depend on the margin.
-// Border handling: OpenCV pads every level by winSize (REFLECT_101 for images, zeros for
-// derivatives).  Level 0 -- the bulk of the bytes and the graded pyramid kernel's output -- is not
-// padded: indices are reflected while staging / extracting.  Levels >= 1 are small and carry the
-// border physically (LevelDev::pad_x / pad_y, written by pad_reflect_kernel), because a third of the
-// windows cross the image edge there and the reflecting paths cost 15 % of this kernel.
+// One kernel shape for every window up to 32 x 32.  A lane owns taps of ONE window column: the window is cut into lane-items of
+// consecutive rows of a column -- windows up to 16 x 16: the whole column (up to 16 taps); other windows: 8 rows, item
+// q = (ty / 8) * win_w + tx.  A point is tracked by a GROUP of 64 / PPW lanes, a lane owns the items hl, hl + LANES, ... (NI of
+// them), and a wave tracks PPW points in lock step:
+//     windows up to 16 x 16 (the bench's 15x15)        PPW = 4   16 lanes = one DPP row per point, lane = column
+//     other windows of <= 32 items (e.g. 8 x 32)        PPW = 2   32 lanes, 1 item per lane
+//     windows of <= 64 items (21 x 21: 63 items)        PPW = 2   32 lanes, 2 items per lane
+//     windows of <= 128 items (the reference's 30x30)   PPW = 1   64 lanes, 2 items per lane
+// Column ownership makes the 16 lanes of a column group load ADJACENT addresses (a wave-instruction touches a handful of cache
+// lines; with a lane per window row it touched 64, and the L1's line rate bound the kernel), and lets tap r reuse the permuted
+// byte pair of row r + 1 as tap r + 1's row r: one v_perm_b32 per row instead of two per tap.
+// All pyramid levels run coarse -> fine inside the wave, the running estimate never leaves registers.  Per level a group
+//   1. stages the J search region (window + RM px margin) from global memory into its private LDS slice with aligned dword
+//      loads -- ONE global round trip per level instead of one per Gauss-Newton iteration;
+//   2. extracts its taps of the template patch (I, Ix, Iy: 14-bit fixed-point bilinear, integer exact) once and keeps them in
+//      registers: per tap the dot accumulator BILIN_ROUND - (I << 9), Ix and Iy as int16 pairs of vertically adjacent taps;
+//   3. iterates out of LDS: per row one ds_read2_b32 + v_perm_b32 (the byte pair of columns c, c + 1), per tap two
+//      v_dot2_i32_i16 (the template value rides in the dot's accumulator, so the dots yield the mismatch directly) and a shift,
+//      mismatches packed in int16 pairs and multiplied onto the packed gradients with v_dot2_i32_i16 again: 5.6 VALU per tap;
+//   4. reduces its sums across its lanes with v_permlane32_swap / v_permlane16_swap / DPP adds (no LDS), solves the 2x2 system
+//      and tests the exit conditions.
+// Everything that is uniform across a group -- window origins, the bilinear weights, the 2x2 solve, the exit tests, the
+// reductions' tails -- is computed once per wave-instruction for PPW points.  The groups run in lock step: a level / an iteration
+// executes while any point of the wave needs it (consecutive points of a frame take the same number of iterations to within a few
+// per cent on the bench's stream), a point that is done sits the rest out under an exec mask, and every cross-lane instruction
+// runs in wave-uniform control flow with all 64 lanes enabled (the swaps and DPP row operations used for a group never leave it).
+// If an iterate leaves the staged region (rare: margin RM px per level) the region is re-staged around it, so results never
+// depend on the margin.
+// Addressing: every level of a frame batch carries OpenCV's winSize border physically (LevelDev::pad_x / pad_y: REFLECT_101
+// pixels written with the upload / by pad_reflect_kernel, zero derivatives), so every window that passes the bounds test is plain
+// memory: one wave-uniform plane base in SGPRs + an unsigned 32-bit lane offset (global_load ... v, s[base]); there is no
+// reflection code.  The run-time-window forms also load (and mask) the rows of the taps below a short window: up to 16 rows
+// past the bottom border, which the batch's allocation carries as slack.
 //
-// Summation order (defines bit-exactness against oracle order DR3O_ORDER_WAVE64): every term is an
-// integer; the taps of one lane are summed exactly in int32 (<= 16 taps of < 2^25.1) and converted
-// to f32 once into p[lane] (OpenCV converts every term and rounds at every add: the kernel's sum is
-// the more accurate one, tests bound the difference); a[l] = p[l] + p[l+32] (l < 32);
-// c[l] = a[l] + a[l+16] (l < 16); an xor butterfly with strides 1,2,4,8 over the 16 values gives the
-// total.  wave_sum2 / wave_sum3 produce exactly that tree for two / three sums at once.  No FMA
-// contraction (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
+// Summation order (defines bit-exactness against the CPU checker's kernel order): every term is an integer; the taps of one
+// lane are summed exactly in int32 (<= 16 taps of < 2^25.1) and converted to f32 once into p[lane] (OpenCV converts every term
+// and rounds at every add: the kernel's sum is the more accurate one, tests bound the difference); 64-lane groups:
+// a[l] = p[l] + p[l+32]; 64- and 32-lane groups: c[l] = a[l] + a[l+16]; all: an xor butterfly with strides 1,2,4,8 over the 16
+// values.  No FMA contraction (-ffp-contract=off), IEEE divide/sqrt (hipcc default).
 #include "dr3hip_internal.h"
 #include "wave_tree.h"
 
@@ -82,28 +86,16 @@ __device__ __forceinline__ Weights make_weights(float a, float b)
     return W;
 }
 
-// Two image rows as aligned 8-byte windows (lo, hi dwords); tap k uses bytes o+k, o+k+1.
-struct Rows { uint32_t lo0, hi0, lo1, hi1; };
-
-// (I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11 + acc) >> (W_BITS - 5): two perms + two dot2.
-// acc = BILIN_ROUND gives CV_DESCALE(..., W_BITS - 5); acc = BILIN_ROUND - (t << (W_BITS - 5)) gives that minus t
-// (the subtrahend is a multiple of the shift's divisor, so floor commutes with it).
+// A bilinear tap: (I00*iw00 + I01*iw01 + I10*iw10 + I11*iw11 + acc) >> (W_BITS - 5), two v_dot2_i32_i16 on the byte pairs of rows
+// y and y + 1.  acc = BILIN_ROUND gives CV_DESCALE(..., W_BITS - 5); acc = BILIN_ROUND - (t << (W_BITS - 5)) gives that minus t
+// (the subtrahend is a multiple of the shift's divisor, so floor commutes with it).  The dots are SIGNED: iw11 = 2^14 - iw00 -
+// iw01 - iw10 is -1 or -2 when both fractions are a few 1e-5 (the three rounded weights then sum to more than 2^14); OpenCV carries
+// it as a negative int, so must the packed 16-bit lane.
 constexpr int BILIN_ROUND = 1 << (W_BITS - 5 - 1);
 // The saturating form of v_dot2_i32_i16 is the three-operand encoding: the accumulator is a free source instead of
 // being tied to the destination (the non-saturating builtin selects v_dot2c and a v_mov per use).  No sum here can
 // reach the int32 limits (bilinear: < 2^31 / 64; window sums: <= 16 taps of < 2^25.1), so saturation never acts.
 constexpr bool DOT_SAT = true;
-__device__ __forceinline__ int bilin_u8(const Rows& r, uint32_t sel, const Weights& W, int acc)
-{
-    const uint32_t p0 = __builtin_amdgcn_perm(r.hi0, r.lo0, sel);
-    const uint32_t p1 = __builtin_amdgcn_perm(r.hi1, r.lo1, sel);
-    // signed dot: iw11 = 2^14 - iw00 - iw01 - iw10 is -1 or -2 when both fractions are a few 1e-5 (the three rounded
-    // weights then sum to more than 2^14); OpenCV carries it as a negative int, so must the packed 16-bit lane
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), acc, DOT_SAT);
-    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, DOT_SAT);
-    return v >> (W_BITS - 5);
-}
-
 // (lo | hi << 16) of two values that fit int16
 __device__ __forceinline__ uint32_t pack_s16(int lo, int hi)
 {
@@ -112,18 +104,6 @@ __device__ __forceinline__ uint32_t pack_s16(int lo, int hi)
 __device__ __forceinline__ int dot_s16(uint32_t a, uint32_t b, int acc)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, DOT_SAT);
-}
-
-// CV_DESCALE(d00*iw00 + d01*iw01 + d10*iw10 + d11*iw11, W_BITS) on one int16 channel of the
-// interleaved derivative; a0,a1 = dwords (Ix | Iy << 16) of columns k, k+1 of row y, b0,b1 of row y+1
-template <uint32_t SEL>
-__device__ __forceinline__ int bilin_s16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const Weights& W)
-{
-    const uint32_t p0 = __builtin_amdgcn_perm(a1, a0, SEL);
-    const uint32_t p1 = __builtin_amdgcn_perm(b1, b0, SEL);
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p0), __builtin_bit_cast(s16x2, W.w01), 1 << (W_BITS - 1), DOT_SAT);
-    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p1), __builtin_bit_cast(s16x2, W.w23), v, DOT_SAT);
-    return v >> W_BITS;
 }
 
 // sums over each group of two / three lane values; every lane receives its own group's totals
@@ -159,15 +139,6 @@ __device__ __forceinline__ gbase_t as_global(const void* p)
     return (gbase_t)(const uint8_t*)p;
 }
 
-// the two aligned dword pairs tap K of a lane-item works on: taps 4j .. 4j+3 use dwords (j, j+1) of both rows, all with the same
-// four byte selectors
-template <int ND>
-__device__ __forceinline__ Rows rows_of(const uint32_t (&ra)[ND], const uint32_t (&rb)[ND], int j)
-{
-    Rows o; o.lo0 = ra[j]; o.hi0 = ra[j + 1]; o.lo1 = rb[j]; o.hi1 = rb[j + 1];
-    return o;
-}
-
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 #ifndef LKG_WAVES
@@ -179,12 +150,6 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef LKG_WAVES_NI2
 #define LKG_WAVES_NI2 4
 #endif
-// q / rpr for a lane-item index q < 512 and rpr in 1..4
-__device__ __forceinline__ int div_rpr(int q, int rpr)
-{
-    return rpr == 1 ? q : rpr == 2 ? q >> 1 : rpr == 4 ? q >> 2 : (q * 171) >> 9;
-}
-
 // WIN > 0: square compile-time window; WIN = 0: run-time window of the group shape PPW x NI (lk_group_shape below)
 template <int WIN, int PPW, int NI>
 // (the run-time forms holding 16 taps per lane need more registers than four waves per SIMD leave them)
