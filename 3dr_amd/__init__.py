@@ -28,6 +28,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "dr3hip.h")
 # constants of include/dr3hip.h
 T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
 LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
+LK_LOST_START_OUTSIDE, LK_LOST_MIN_EIG, LK_LOST_ITERATE_OUTSIDE, LK_LOST_RESULT_OUTSIDE = 1, 2, 3, 4
 WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
@@ -46,6 +47,13 @@ class LKParams(C.Structure):
     _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int),
                 ("crit_type", C.c_int), ("max_iters", C.c_int), ("eps", C.c_double),
                 ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
+
+
+class LKCounters(C.Structure):
+    _fields_ = [("n_points", C.c_ulonglong), ("n_tracked", C.c_ulonglong),
+                ("n_lost_start_outside", C.c_ulonglong), ("n_lost_min_eig", C.c_ulonglong),
+                ("n_lost_iterate_outside", C.c_ulonglong), ("n_lost_result_outside", C.c_ulonglong),
+                ("iters_total", C.c_ulonglong), ("iters_hist", C.c_ulonglong * 32)]
 
 
 class AlignParams(C.Structure):
@@ -124,6 +132,7 @@ def _signatures():
         "dr3hip_last_error": ([vp], C.c_char_p),
         "dr3hip_sync": ([vp], ip),
         "dr3hip_stream": ([vp], vp),
+        "dr3hip_set_stream": ([vp, vp], ip),
         "dr3hip_malloc": ([vp, C.c_size_t, P(vp)], ip),
         "dr3hip_free": ([vp, vp], ip),
         "dr3hip_memcpy_h2d": ([vp, vp, vp, C.c_size_t], ip),
@@ -144,6 +153,8 @@ def _signatures():
         "dr3hip_batch_pad_level0": ([vp, ip, ip], ip),
         "dr3hip_batch_build": ([vp, ip, ip, ip], ip),
         "dr3hip_batch_track": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, P(LKParams)], ip),
+        "dr3hip_batch_track_diag": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, vp, P(LKParams)], ip),
+        "dr3hip_lk_stats": ([vp, C.c_longlong, vp, vp, vp, ip, P(LKCounters)], ip),
         "dr3hip_batch_align": ([vp, ip, ip, vp, vp, vp, ip, P(AlignParams), vp, vp, vp, vp], ip),
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
@@ -296,6 +307,24 @@ class Context:
 
     def sync(self):
         self._chk(lib().dr3hip_sync(self.h))
+
+    def lk_stats(self, n_points, d_status, d_reason=None, d_iters=None, levels=0):
+        """the tracker's counters over device-resident outputs (dr3hip_lk_stats) as a dict"""
+        ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        c = LKCounters()
+        self._chk(lib().dr3hip_lk_stats(self.h, int(n_points), ptr(d_status), ptr(d_reason), ptr(d_iters), int(levels), C.byref(c)))
+        out = {k: int(getattr(c, k)) for k, _ in LKCounters._fields_ if k != "iters_hist"}
+        out["iters_hist"] = [int(v) for v in c.iters_hist]
+        return out
+
+    def stream(self):
+        """the hipStream_t (as an integer) the context enqueues on"""
+        return lib().dr3hip_stream(self.h) or 0
+
+    def set_stream(self, hip_stream):
+        """enqueue everything on the caller's hipStream_t from now on (an integer handle);
+        None / 0 returns to the context's own stream"""
+        self._chk(lib().dr3hip_set_stream(self.h, C.c_void_p(int(hip_stream)) if hip_stream else None))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -588,9 +617,14 @@ class FrameBatch:
                                                int(n_pts), C.byref(params), ptr(d_T), ptr(d_n_meas), ptr(d_chi2), ptr(d_iters)))
 
     def track(self, n_pairs, first_slot, d_prev_xy, d_next_xy, n_pts, d_status, d_err, params,
-              d_prev_slot=None, d_next_slot=None, d_iters=None):
-        """all d_* are DeviceBuffer (or raw device pointers); returns the effective maxLevel"""
+              d_prev_slot=None, d_next_slot=None, d_iters=None, d_reason=None):
+        """all d_* are DeviceBuffer (or raw device pointers); returns the effective maxLevel.  d_reason (n_pairs x n_pts bytes)
+        receives the LK_LOST_* code of every point (dr3hip_batch_track_diag)."""
         ptr = lambda b: None if b is None else (b.ptr if isinstance(b, DeviceBuffer) else b)
+        if d_reason is not None:
+            return self.ctx._chk(lib().dr3hip_batch_track_diag(self.h, n_pairs, first_slot, ptr(d_prev_slot), ptr(d_next_slot),
+                                                               ptr(d_prev_xy), ptr(d_next_xy), n_pts, ptr(d_status),
+                                                               ptr(d_err), ptr(d_iters), ptr(d_reason), C.byref(params)))
         return self.ctx._chk(lib().dr3hip_batch_track(self.h, n_pairs, first_slot, ptr(d_prev_slot), ptr(d_next_slot),
                                                       ptr(d_prev_xy), ptr(d_next_xy), n_pts, ptr(d_status),
                                                       ptr(d_err), ptr(d_iters), C.byref(params)))

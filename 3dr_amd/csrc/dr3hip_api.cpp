@@ -22,7 +22,8 @@ struct ProfEvent { int which; hipEvent_t e0, e1; };
 
 struct dr3hip_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream every launch and copy goes to: own_stream, or the caller's (dr3hip_set_stream)
+    hipStream_t own_stream = nullptr;
     std::string err;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // grow-only staging buffers for the host-buffer calls
@@ -192,6 +193,7 @@ int dr3hip_init(int device, dr3hip_ctx** out)
         delete ctx;
         return DR3HIP_EHIP;
     }
+    ctx->own_stream = ctx->stream;
     *out = ctx;
     return DR3HIP_OK;
 }
@@ -208,7 +210,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -223,6 +225,17 @@ int dr3hip_sync(dr3hip_ctx* ctx)
 }
 
 void* dr3hip_stream(dr3hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    // work already enqueued keeps its order: the old stream is drained (and its timing events read) before the switch
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    prof_drain(ctx);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return DR3HIP_OK;
+}
 
 int dr3hip_malloc(dr3hip_ctx* ctx, size_t bytes, void** dptr)
 {
@@ -1109,6 +1122,15 @@ int dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
                        const float* d_prev_xy, float* d_next_xy, int n_pts,
                        uint8_t* d_status, float* d_err, int* d_iters, const dr3hip_lk_params* p)
 {
+    return dr3hip_batch_track_diag(b, n_pairs, first_slot, d_prev_slot, d_next_slot, d_prev_xy, d_next_xy, n_pts, d_status, d_err,
+                                   d_iters, nullptr, p);
+}
+
+int dr3hip_batch_track_diag(dr3hip_batch* b, int n_pairs, int first_slot,
+                            const int* d_prev_slot, const int* d_next_slot,
+                            const float* d_prev_xy, float* d_next_xy, int n_pts,
+                            uint8_t* d_status, float* d_err, int* d_iters, uint8_t* d_reason, const dr3hip_lk_params* p)
+{
     if (!b) return DR3HIP_EINVAL;
     dr3hip_ctx* ctx = b->ctx;
     if (!p || n_pairs < 0 || n_pts < 0 || !d_prev_xy || !d_next_xy || !d_status || !d_err)
@@ -1132,10 +1154,33 @@ int dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
         a.prev_xy = d_prev_xy + 2 * off; a.next_xy = d_next_xy + 2 * off;
         a.status = d_status + off; a.err = d_err + off;
         a.iters = d_iters ? d_iters + off * (L + 1) : nullptr;
+        a.reason = d_reason ? d_reason + off : nullptr;
         HIPCHK(ctx, launch_lk_track(a, n, ctx->stream));
     }
     prof_end(ctx, pe);
     return L;
+}
+
+int dr3hip_lk_stats(dr3hip_ctx* ctx, long long n_points, const uint8_t* d_status, const uint8_t* d_reason,
+                    const int* d_iters, int levels, dr3hip_lk_counters* out)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!out || n_points < 0 || !d_status || (d_iters && (levels < 1 || levels > DR3HIP_MAX_LEVELS)))
+        return fail(ctx, DR3HIP_EINVAL, "lk_stats: bad arguments");
+    memset(out, 0, sizeof(*out));
+    out->n_points = n_points;
+    if (n_points == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    int rc;
+    const size_t words = sizeof(dr3hip_lk_counters) / sizeof(unsigned long long);
+    if ((rc = stage_reserve(ctx, 3, words * sizeof(unsigned long long)))) return rc;
+    unsigned long long* d_cnt = (unsigned long long*)ctx->stage[3].p;
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, words * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, launch_lk_stats(n_points, d_status, d_reason, d_iters, d_iters ? levels : 0, d_cnt, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, d_cnt, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_points = n_points;
+    return DR3HIP_OK;
 }
 
 // ---- sparse image alignment (extension) -----------------------------------------------------------------

@@ -57,6 +57,7 @@ struct LKArgs {
     uint8_t* status;
     float* err;
     int* iters;
+    uint8_t* reason;       // optional: DR3HIP_LK_LOST_* per point (0 = tracked)
 };
 
 struct WarpJobDev {
@@ -166,6 +167,9 @@ hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s);
 hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
+// counters over the tracker's outputs: cnt = the unsigned long long fields of dr3hip_lk_counters in declaration order
+hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* reason, const int* iters, int levels,
+                           unsigned long long* cnt, hipStream_t s);
 hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);

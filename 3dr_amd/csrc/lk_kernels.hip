@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     const int sc = hl & (COLS - 1), sr = hl / COLS;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;
 
-    int   status = 1;
+    int   lost = 0;                // 0 = tracked, else the DR3HIP_LK_LOST_* reason (status = !lost)
     float err = 0.f;
 
     for (int level = a.max_level; level >= 0; --level) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
         const int ipx = floor_to_int(fpx), ipy = floor_to_int(fpy);
         // -win <= ip < size  <=>  (unsigned)(ip + win) < (unsigned)(size + win)
         bool act = (unsigned)(ipx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(ipy + win_h) < (unsigned)(Lh + win_h);
-        if (!act && level == 0) { status = 0; err = 0.f; }
+        if (!act && level == 0) { lost = DR3HIP_LK_LOST_START_OUTSIDE; err = 0.f; }
         if (!any_lane(act)) {
             if (a.iters && hl == 0 && pt_ok) a.iters[pidx * (a.max_level + 1) + level] = 0;
             continue;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
         if (act) {
             if (a.flags & DR3HIP_LK_GET_MIN_EIGENVALS) err = minEig;
             if ((double)minEig < a.min_eig || D < 1.1920928955078125e-7f /* FLT_EPSILON */) {
-                if (level == 0) status = 0;
+                if (level == 0) lost = DR3HIP_LK_LOST_MIN_EIG;
                 act = false;
             }
         }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
                 fcx = floorf(cx); fcy = floorf(cy);
                 inx = floor_to_int(fcx); iny = floor_to_int(fcy);
                 if (!((unsigned)(inx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(iny + win_h) < (unsigned)(Lh + win_h))) {
-                    if (level == 0) status = 0;
+                    if (level == 0) lost = DR3HIP_LK_LOST_ITERATE_OUTSIDE;
                     act = false;
                 }
             }
@@ -430,11 +430,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
 
         // ---- residual (level 0 only) -----------------------------------------------------------------
         if (level == 0 && !(a.flags & DR3HIP_LK_GET_MIN_EIGENVALS)) {
-            bool res = status != 0;
+            bool res = lost == 0;
             const float fx = nx - half_x, fy = ny - half_y;
             const float ffx = floorf(fx), ffy = floorf(fy);
             const int inx = floor_to_int(ffx), iny = floor_to_int(ffy);
-            if (res && !((unsigned)(inx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(iny + win_h) < (unsigned)(Lh + win_h))) { status = 0; res = false; }
+            if (res && !((unsigned)(inx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(iny + win_h) < (unsigned)(Lh + win_h))) { lost = DR3HIP_LK_LOST_RESULT_OUTSIDE; res = false; }
             int se = 0;
             if (res) {
                 uint32_t dxb = (uint32_t)((inx & ~3) - rx0), dyr = (uint32_t)(iny - ry0);
@@ -481,12 +481,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     if (hl == 0 && pt_ok) {
         a.next_xy[2 * pidx] = nx;
         a.next_xy[2 * pidx + 1] = ny;
-        a.status[pidx] = (uint8_t)status;
+        a.status[pidx] = (uint8_t)(lost == 0);
+        if (a.reason) a.reason[pidx] = (uint8_t)lost;
         a.err[pidx] = err;
     }
 }
 
 }  // namespace
+
+// ---- counters over the tracker's outputs (dr3hip_lk_stats): per-wave ballots / LDS histogram, one atomic per counter and block -----
+namespace {
+__global__ __launch_bounds__(256) void lk_stats_kernel(long long n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ reason,
+                                                       const int* __restrict__ iters, int levels, unsigned long long* __restrict__ cnt)
+{
+    constexpr int NC = 6 + 32;                  // c[j] = field j + 1 of dr3hip_lk_counters: tracked, 4 reasons, iters_total, 32 bins
+    __shared__ unsigned int c[NC];
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) c[i] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (status[i]) atomicAdd(&c[0], 1u);
+        const int r = reason ? reason[i] : 0;
+        if (r >= 1 && r <= 4) atomicAdd(&c[r], 1u);
+        for (int l = 0; l < levels; ++l) {
+            const int k = iters[i * levels + l];
+            atomicAdd(&c[5], (unsigned)(k < 0 ? 0 : k));
+            atomicAdd(&c[6 + (k < 0 ? 0 : k < 31 ? k : 31)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NC; i += blockDim.x)
+        if (c[i]) atomicAdd(&cnt[i + 1], (unsigned long long)c[i]);
+}
+}  // namespace
+
+hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* reason, const int* iters, int levels,
+                           unsigned long long* cnt, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(lk_stats_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, n, status, reason, iters, levels, cnt);
+    return hipGetLastError();
+}
 
 // group shape by window (the CPU checker's summation-order rule is the same): points per wave ppw (64 / ppw lanes per point) and
 // lane-items per lane ni

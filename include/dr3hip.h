@@ -85,6 +85,10 @@ void        dr3hip_destroy(dr3hip_ctx* ctx);
 const char* dr3hip_last_error(const dr3hip_ctx* ctx);        /* ctx may be NULL: last init error */
 int         dr3hip_sync(dr3hip_ctx* ctx);                    /* wait for the ctx stream */
 void*       dr3hip_stream(dr3hip_ctx* ctx);                  /* the hipStream_t kernels are launched on */
+/* Caller-stream form of every "device" call (SURVEY 8b's _async variants): from now on the context enqueues its kernels, copies
+ * and collectives on hip_stream (a hipStream_t of the context's device, owned by the caller); NULL returns to the context's own
+ * stream.  Work already enqueued is waited for first, so the order of the caller's calls is kept across the switch. */
+int         dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream);
 
 /* device memory helpers so that a C/Go/Java caller needs no HIP headers */
 int dr3hip_malloc(dr3hip_ctx* ctx, size_t bytes, void** dptr);
@@ -174,6 +178,32 @@ int  dr3hip_batch_track(dr3hip_batch* b, int n_pairs, int first_slot,
                         const float* d_prev_xy, float* d_next_xy, int n_pts,
                         uint8_t* d_status, float* d_err, int* d_iters,
                         const dr3hip_lk_params* p);
+
+/* Why a point was lost (status 0), one byte per point; 0 = tracked.  OpenCV reports only the status; these are the four places
+ * LKTrackerInvoker clears it. */
+#define DR3HIP_LK_LOST_START_OUTSIDE    1   /* the template window at the previous position lies outside level 0 */
+#define DR3HIP_LK_LOST_MIN_EIG          2   /* level 0: minimum eigenvalue below the threshold, or determinant < FLT_EPSILON */
+#define DR3HIP_LK_LOST_ITERATE_OUTSIDE  3   /* level 0: an iterate's window left the image */
+#define DR3HIP_LK_LOST_RESULT_OUTSIDE   4   /* level 0: the final position's window (residual) lies outside the image */
+
+/* dr3hip_batch_track plus d_reason (device, n_pairs x n_pts bytes, may be NULL): the DR3HIP_LK_LOST_* code of every point. */
+int  dr3hip_batch_track_diag(dr3hip_batch* b, int n_pairs, int first_slot,
+                             const int* d_prev_slot, const int* d_next_slot,
+                             const float* d_prev_xy, float* d_next_xy, int n_pts,
+                             uint8_t* d_status, float* d_err, int* d_iters, uint8_t* d_reason, const dr3hip_lk_params* p);
+
+/* The tracker's counters as a result struct (what the reference logs around its LK call, src/initialization.cpp:652-654):
+ * one reduction over device-resident outputs of dr3hip_batch_track(_diag).  d_reason and d_iters may be NULL (their counters stay
+ * 0); d_iters is n_points x levels as dr3hip_batch_track writes it.  iters_hist[k] counts the (point, level) entries that took k
+ * iterations, the last bin k >= 31.  Synchronous on return. */
+typedef struct dr3hip_lk_counters {
+    unsigned long long n_points, n_tracked;
+    unsigned long long n_lost_start_outside, n_lost_min_eig, n_lost_iterate_outside, n_lost_result_outside;
+    unsigned long long iters_total;
+    unsigned long long iters_hist[32];
+} dr3hip_lk_counters;
+int  dr3hip_lk_stats(dr3hip_ctx* ctx, long long n_points, const uint8_t* d_status, const uint8_t* d_reason,
+                     const int* d_iters, int levels, dr3hip_lk_counters* out);
 
 /* ---- device-resident warp (BASELINE config 3: panorama tiles) ----------------------------- */
 
