@@ -330,7 +330,7 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
         lw[l] = l ? lw[l - 1] / 2 : w; lh[l] = l ? lh[l - 1] / 2 : h;
         lp[l] = l ? lw[l] : stride;
         off[l] = total;
-        total += (size_t)align_up(lp[l] * lh[l] + 64, 256);
+        total += (size_t)align_up((long long)lp[l] * lh[l] + 64, 256ll);
     }
     const int sp = align_up(w, 64);
     const size_t cells_off = (size_t)align_up(n_cells, 256);          // stage[6]: occupancy bytes, then the cell keys
@@ -410,13 +410,13 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
         int lw = w, lh = h;
         for (int l = 1; l < n_levels; ++l) {
             lw /= 2; lh /= 2;
-            D.hs_step[l] = (long long)align_up(lw * lh + 64, 256);
+            D.hs_step[l] = align_up((long long)lw * lh + 64, 256ll);
             void* p = nullptr;
             if (hipMalloc(&p, (size_t)D.hs_step[l] * b->capacity + 256) != hipSuccess) return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (level %d)", l);
             D.hs[l] = (uint8_t*)p; b->bytes += (size_t)D.hs_step[l] * b->capacity + 256;
         }
         D.spitch = align_up(w, 64);
-        D.score_step = (long long)align_up(D.spitch * h, 256);
+        D.score_step = align_up((long long)D.spitch * h, 256ll);
         void *ps = nullptr, *pk = nullptr;
         if (hipMalloc(&ps, (size_t)D.score_step * b->capacity + 256) != hipSuccess ||
             hipMalloc(&pk, sizeof(unsigned long long) * (size_t)n_cells * b->capacity) != hipSuccess) {
@@ -1302,7 +1302,7 @@ int dr3hip_halfsample_pyramid(dr3hip_ctx* ctx, const uint8_t* img, int w, int h,
         // (stride == cols) and level 0 has the caller's stride; mirror both.
         lp[l] = (l == 0) ? stride : lw[l];
         off[l] = total;
-        total += (size_t)align_up(lp[l] * (lh[l] > 0 ? lh[l] : 1) + 64, 256);
+        total += (size_t)align_up((long long)lp[l] * (lh[l] > 0 ? lh[l] : 1) + 64, 256ll);
     }
     if ((rc = stage_reserve(ctx, 4, total))) return rc;
     uint8_t* base = (uint8_t*)ctx->stage[4].p;
@@ -1404,7 +1404,7 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
     bool generic = false;
     for (int i = 0; i < n_jobs; ++i) {
         const dr3hip_warp_job& q = jobs[i];
-        if (!q.src || !q.dst || q.sw < 1 || q.sh < 1 || q.dw < 1 || q.dh < 1 || q.sstride < q.sw * esz || q.dstride < q.dw * esz)
+        if (!q.src || !q.dst || !side_ok(q.sw) || !side_ok(q.sh) || !side_ok(q.dw) || !side_ok(q.dh) || q.sstride < q.sw * esz || q.dstride < q.dw * esz)
             return fail(ctx, DR3HIP_EINVAL, "warp_batch: job %d has bad geometry", i);
         if (esz >= 4 && (((uintptr_t)q.src | (uintptr_t)q.dst | (uintptr_t)q.sstride | (uintptr_t)q.dstride) & (uintptr_t)(esz - 1)))
             return fail(ctx, DR3HIP_EINVAL, "warp_batch: job %d pointers/strides must be %d-byte aligned", i, esz);
@@ -1429,7 +1429,7 @@ int dr3hip_warp_perspective(dr3hip_ctx* ctx, const void* src, int sw, int sh, in
 {
     if (!ctx) return DR3HIP_EINVAL;
     const int esz = type_elem_bytes(type);
-    if (!src || !dst || !M || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw * esz || dstride < dw * esz)
+    if (!src || !dst || !M || esz == 0 || !side_ok(sw) || !side_ok(sh) || !side_ok(dw) || !side_ok(dh) || sstride < sw * esz || dstride < dw * esz)
         return fail(ctx, DR3HIP_EINVAL, "warp_perspective: bad arguments");
     DeviceGuard g(ctx->device);
     const int sp = align_up(sw * esz, 64), dp = align_up(dw * esz, 64);
@@ -1452,7 +1452,7 @@ int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx, const void* d_src, int sw, int sh
 {
     if (!ctx) return DR3HIP_EINVAL;
     const int esz = type_elem_bytes(type);
-    if (!d_src || !d_dst || !d_mapx || !d_mapy || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 ||
+    if (!d_src || !d_dst || !d_mapx || !d_mapy || esz == 0 || !side_ok(sw) || !side_ok(sh) || !side_ok(dw) || !side_ok(dh) ||
         sstride < sw * esz || dstride < dw * esz || map_stride < dw * 4 || (map_stride & 3))
         return fail(ctx, DR3HIP_EINVAL, "remap: bad arguments");
     if (esz >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst | (uintptr_t)sstride | (uintptr_t)dstride) & (uintptr_t)(esz - 1)))
@@ -1475,7 +1475,7 @@ int dr3hip_warp_local_dev(dr3hip_ctx* ctx, const void* d_src, int w, int h, int 
 {
     if (!ctx) return DR3HIP_EINVAL;
     const int esz = type_elem_bytes(type);
-    if (!d_src || !d_dst || esz == 0 || w < 1 || h < 1 || sstride < w * esz || dstride < w * esz ||
+    if (!d_src || !d_dst || esz == 0 || !side_ok(w) || !side_ok(h) || sstride < w * esz || dstride < w * esz ||
         (kind != DR3HIP_WARP_SPHERICAL && kind != DR3HIP_WARP_CYLINDRICAL))
         return fail(ctx, DR3HIP_EINVAL, "warp_local: bad arguments");
     if (esz >= 4 && (((uintptr_t)d_src | (uintptr_t)d_dst | (uintptr_t)sstride | (uintptr_t)dstride) & (uintptr_t)(esz - 1)))
@@ -1518,7 +1518,7 @@ int dr3hip_warp_local(dr3hip_ctx* ctx, const void* src, int w, int h, int sstrid
 {
     if (!ctx) return DR3HIP_EINVAL;
     const int esz = type_elem_bytes(type);
-    if (!src || !dst || esz == 0 || w < 1 || h < 1 || sstride < w * esz || dstride < w * esz)
+    if (!src || !dst || esz == 0 || !side_ok(w) || !side_ok(h) || sstride < w * esz || dstride < w * esz)
         return fail(ctx, DR3HIP_EINVAL, "warp_local: bad arguments");
     DeviceGuard g(ctx->device);
     const int sp = align_up(w * esz, 64);
@@ -1537,7 +1537,7 @@ int dr3hip_remap_bilinear(dr3hip_ctx* ctx, const void* src, int sw, int sh, int 
 {
     if (!ctx) return DR3HIP_EINVAL;
     const int esz = type_elem_bytes(type);
-    if (!src || !dst || !mapx || !mapy || esz == 0 || sw < 1 || sh < 1 || dw < 1 || dh < 1 ||
+    if (!src || !dst || !mapx || !mapy || esz == 0 || !side_ok(sw) || !side_ok(sh) || !side_ok(dw) || !side_ok(dh) ||
         sstride < sw * esz || dstride < dw * esz || map_stride < dw * 4)
         return fail(ctx, DR3HIP_EINVAL, "remap: bad arguments");
     DeviceGuard g(ctx->device);

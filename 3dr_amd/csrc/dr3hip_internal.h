@@ -184,6 +184,8 @@ hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 
 // geometry helpers shared by host and launchers
+// image sides the entry points accept: row bytes (side x 16-byte pixels) and 2 x side then stay inside int
+static inline bool side_ok(int v) { return v >= 1 && v <= (1 << 26); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 static inline int type_channels(int type) {
