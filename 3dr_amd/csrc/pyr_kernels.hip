@@ -16,10 +16,15 @@
 namespace dr3 {
 namespace {
 
-constexpr int TW = 128;            // tile width  (level-l pixels), multiple of 8
-constexpr int TH = 32;             // tile height, even
+#ifndef PYR_TW
+#define PYR_TW 128
+#define PYR_TH 32
+#endif
+constexpr int TW = PYR_TW;         // tile width  (level-l pixels), multiple of 8
+constexpr int TH = PYR_TH;         // tile height, even; TW * TH = 4096 (the thread maps below)
 constexpr int LW = TW + 8;         // LDS bytes used per row: x0-4 .. x0+TW+3
-constexpr int LP = 144;            // LDS row pitch in bytes (multiple of 8)
+constexpr int LP = TW + 16;        // LDS row pitch in bytes (multiple of 8)
+static_assert(TW * TH == 4096 && TW % 8 == 0 && TH % 2 == 0, "tile shape");
 constexpr int LR = TH + 4;         // LDS rows: y0-2 .. y0+TH+1
 constexpr int NT = 256;
 
@@ -130,8 +135,15 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
                 // zero the lanes' pixels beyond w so the pitch slack stays deterministic
 #pragma unroll
                 for (int k = 1; k < 4; ++k) if (x + k >= w) o[k] = 0;
-                uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-                *reinterpret_cast<uint4*>(der + (long long)y * a.src.dpitch + 4 * x) = v;
+                // written once, read by the tracker launches later from HBM: a non-temporal store (no L2 allocation) moves this
+                // 80 % of the kernel's bytes a quarter faster than a plain one (0.155 -> 0.118 ms for the level-0 launch)
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = {o[0], o[1], o[2], o[3]};
+#ifndef PYR_PLAIN_STORE
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(der + (long long)y * a.src.dpitch + 4 * x));
+#else
+                *reinterpret_cast<u32x4_t*>(der + (long long)y * a.src.dpitch + 4 * x) = v;
+#endif
             }
         }
     }
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
                 const uint32_t v = (X + k < dw) ? (acc[k] >> 8) : 0u;
                 o |= v << (8 * k);
             }
-            *reinterpret_cast<uint32_t*>(dst + (long long)Y * a.dst.pitch + X) = o;
+            *reinterpret_cast<uint32_t*>(dst + (long long)Y * a.dst.pitch + X) = o;     // read again by the next level's launch: a plain store
         }
     }
 }

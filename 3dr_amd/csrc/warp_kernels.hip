@@ -25,6 +25,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ const DR3_G T* gcast(gcu8 p) { return reinterpret_cast<const DR3_G T*>(p); }
 template <class T> __device__ __forceinline__ DR3_G T* gcast(gu8 p) { return reinterpret_cast<DR3_G T*>(p); }
 
+// destination stores of the gather kernels: every output byte is written once and not read again by the launch, so it is
+// stored non-temporally (no L2 allocation; 2-4 % on the warps, measured in profiles/r02_warp/README.md)
+#ifndef DR3_WARP_PLAIN_STORE
+template <class T> __device__ __forceinline__ void st_out(DR3_G T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ void st_out(DR3_G T* p, T v) { *p = v; }
+#endif
+// a source that the launch reads exactly once (the canvas of the normalise pass): a non-temporal load, 0.330 -> 0.264 ms there
+template <class T> __device__ __forceinline__ T ld_once(const DR3_G T* p) { return __builtin_nontemporal_load(p); }
+
 struct Tap { int sx, sy, fx, fy; };
 
 __device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
@@ -339,7 +349,7 @@ __device__ __forceinline__ void quad_8u(gcu8 __restrict__ src, int sw, int sh, i
             const uint32_t gr1 = __builtin_amdgcn_perm(aR[1], aG[1], 0x0c0c0602u), bg2 = __builtin_amdgcn_perm(aG[2], aB[2], 0x0c0c0602u);
             const uint32_t rb2 = __builtin_amdgcn_perm(aB[3], aR[2], 0x0c0c0602u), gr3 = __builtin_amdgcn_perm(aR[3], aG[3], 0x0c0c0602u);
             DR3_G uint32_t* o = gcast<uint32_t>(row);
-            o[0] = bg0 | (rb0 << 16); o[1] = gr1 | (bg2 << 16); o[2] = rb2 | (gr3 << 16);
+            st_out(o, bg0 | (rb0 << 16)); st_out(o + 1, gr1 | (bg2 << 16)); st_out(o + 2, rb2 | (gr3 << 16));
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -351,7 +361,7 @@ __device__ __forceinline__ void quad_8u(gcu8 __restrict__ src, int sw, int sh, i
         for (int i = 0; i < 4; ++i) a[i] = (full || x + i < dw) ? pixel_8uc1(src, sw, sh, sstride, t[i]) : 0u;
         if (full && dst_aligned) {
             const uint32_t lo = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(a[3], a[2], 0x0c0c0602u);
-            *gcast<uint32_t>(row) = lo | (hi << 16);
+            st_out(gcast<uint32_t>(row), lo | (hi << 16));
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (x + i < dw) row[i] = (uint8_t)byte2(a[i]);
@@ -382,7 +392,7 @@ __device__ __forceinline__ void single_px(gcu8 __restrict__ src, int sw, int sh,
         o.y = v0.y * w[0] + v1.y * w[1] + v2.y * w[2] + v3.y * w[3];
         o.z = v0.z * w[0] + v1.z * w[1] + v2.z * w[2] + v3.z * w[3];
         o.w = v0.w * w[0] + v1.w * w[1] + v2.w * w[2] + v3.w * w[3];
-        gcast<f32x4>(row)[x] = o;
+        st_out(gcast<f32x4>(row) + x, o);
     } else if (TYPE == DR3HIP_32FC1) {
         float w[4]; weights_32f(t.fx, t.fy, w);
         const float v0 = (x0ok && y0ok) ? gcast<float>(r0)[sx] : 0.f;
@@ -404,7 +414,7 @@ __device__ __forceinline__ void single_px(gcu8 __restrict__ src, int sw, int sh,
         blend8_row2(__builtin_amdgcn_perm(v3, v2, 0x07030602u), b, h12, h13);
         const uint32_t c01 = __builtin_amdgcn_perm(blend8_vert(h01, h11, b), blend8_vert(h00, h10, b), 0x0c0c0602u);
         const uint32_t c23 = __builtin_amdgcn_perm(blend8_vert(h03, h13, b), blend8_vert(h02, h12, b), 0x0c0c0602u);
-        gcast<uint32_t>(row)[x] = c01 | (c23 << 16);
+        st_out(gcast<uint32_t>(row) + x, c01 | (c23 << 16));
     }
 }
 
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(256) void stitch_compose_kernel(const StitchArgs a)
     if (x + 3 < a.dw && ((reinterpret_cast<uintptr_t>(a.dst) | (uintptr_t)a.dstride) & 3) == 0) {
         DR3_G uint32_t* q = gcast<uint32_t>(row);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) q[d] = o[4 * d] | (o[4 * d + 1] << 8) | (o[4 * d + 2] << 16) | (o[4 * d + 3] << 24);
+        for (int d = 0; d < 3; ++d) st_out(q + d, o[4 * d] | (o[4 * d + 1] << 8) | (o[4 * d + 2] << 16) | (o[4 * d + 3] << 24));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(256) void panorama_normalize_kernel(const PanoNormA
         const int i = 64 * j + lane;
         uint32_t px = 0u;
         if (xw + i < a.cw) {
-            const f32x4 c4 = cp[i];
+            const f32x4 c4 = ld_once(cp + i);
             if (c4.w > 0.0f) {
                 const uint32_t b = (uint32_t)(int)((float)(int)c4.x / c4.w) & 0xffu;
                 const uint32_t g = (uint32_t)(int)((float)(int)c4.y / c4.w) & 0xffu;
@@ -639,9 +649,9 @@ __global__ __launch_bounds__(256) void panorama_normalize_kernel(const PanoNormA
     gu8 row = (gu8)a.out + (long long)y * a.ostride + (long long)x * 3;
     if (x + 3 < a.cw && ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.ostride) & 3) == 0) {
         DR3_G uint32_t* o = gcast<uint32_t>(row);
-        o[0] = __builtin_amdgcn_perm(d.y, d.x, 0x04020100u);
-        o[1] = __builtin_amdgcn_perm(d.z, d.y, 0x05040201u);
-        o[2] = __builtin_amdgcn_perm(d.w, d.z, 0x06050402u);
+        st_out(o, __builtin_amdgcn_perm(d.y, d.x, 0x04020100u));
+        st_out(o + 1, __builtin_amdgcn_perm(d.z, d.y, 0x05040201u));
+        st_out(o + 2, __builtin_amdgcn_perm(d.w, d.z, 0x06050402u));
     } else {
         const uint32_t px[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
