@@ -18,7 +18,7 @@
 using namespace dr3;
 
 // -------------------------------------------------------------------------------------------------
-struct ProfEvent { int which; hipEvent_t e0, e1; };
+struct ProfEvent { int which; hipEvent_t e0, e1; bool own0, own1; };     // own = false: the event belongs to another pending entry
 
 struct dr3hip_ctx {
     int device = -1;
@@ -127,8 +127,28 @@ static void prof_begin(dr3hip_ctx* ctx, int which, ProfEvent& pe)
         if (!ctx->ev_pool.empty()) { *ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
         else if (hipEventCreate(ev[i]) != hipSuccess) { if (i) ctx->ev_pool.push_back(pe.e0); return; }
     }
-    pe.which = which;
+    pe.which = which; pe.own0 = pe.own1 = true;
     (void)hipEventRecord(pe.e0, ctx->stream);
+}
+// The hot slots (pyramid pass, tracker) do not put event packets between their kernels: their events ride on the kernel
+// dispatches themselves (hipExtLaunchKernelGGL start / stop events = the dispatch's own timestamps).  prof_open only takes the
+// events; the launches record them; prof_close queues the pair for prof_drain.  share0: use this event as e0 (the begin of an
+// enclosing slot whose first kernel is also this slot's).
+static void prof_open(dr3hip_ctx* ctx, int which, ProfEvent& pe, hipEvent_t share0 = nullptr)
+{
+    pe.which = -1; pe.e0 = pe.e1 = nullptr; pe.own0 = share0 == nullptr; pe.own1 = true;
+    if (!ctx->prof || which < 0) return;
+    hipEvent_t* ev[2] = {&pe.e0, &pe.e1};
+    for (int i = share0 ? 1 : 0; i < 2; ++i) {
+        if (!ctx->ev_pool.empty()) { *ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else if (hipEventCreate(ev[i]) != hipSuccess) { if (i && !share0) ctx->ev_pool.push_back(pe.e0); pe.e0 = pe.e1 = nullptr; return; }
+    }
+    if (share0) pe.e0 = share0;
+    pe.which = which;
+}
+static void prof_close(dr3hip_ctx* ctx, ProfEvent& pe)
+{
+    if (pe.which >= 0) ctx->pending.push_back(pe);
 }
 static void prof_end(dr3hip_ctx* ctx, ProfEvent& pe)
 {
@@ -143,7 +163,8 @@ static void prof_drain(dr3hip_ctx* ctx)
         if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
             ctx->prof_ms[pe.which] += ms; ctx->prof_n[pe.which] += 1;
         }
-        ctx->ev_pool.push_back(pe.e0); ctx->ev_pool.push_back(pe.e1);
+        if (pe.own0) ctx->ev_pool.push_back(pe.e0);
+        if (pe.own1) ctx->ev_pool.push_back(pe.e1);
     }
     ctx->pending.clear();
 }
@@ -1072,27 +1093,40 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
     dr3hip_ctx* ctx = b->ctx;
     if (count == 0) return DR3HIP_OK;
     DeviceGuard g(ctx->device);
-    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PYR, pe);
     const int L = b->levels - 1;
+    // the launches of the pass: the level kernels (chunks of 32768 slots keep tiles * slots far below 2^31 blocks), then the physical
+    // REFLECT_101 border of the levels this pass produced (read by the tracker only, never by the pyramid kernels): one launch per
+    // chunk; level 0 got its border when the frame was uploaded (dr3hip_batch_upload)
+    struct Step { int level, s0; };                         // level < 0: the border launch
+    std::vector<Step> steps;
     for (int l = 0; l <= L; ++l) {
-        const bool down = l < L, deriv = with_deriv != 0;
-        if (!down && !deriv) continue;
-        for (int s0 = 0; s0 < count; s0 += 32768) {            // keeps tiles * slots far below 2^31 blocks
-            PyrArgs a;
-            a.src = b->lv[l];
-            a.dst = down ? b->lv[l + 1] : b->lv[l];
-            a.first = first + s0;
-            const int n = count - s0 < 32768 ? count - s0 : 32768;
-            ProfEvent p0; prof_begin(ctx, l == 0 ? DR3HIP_PROF_PYR_L0 : -1, p0);
-            HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream));
-            prof_end(ctx, p0);
-        }
+        if (l == L && !with_deriv) continue;
+        for (int s0 = 0; s0 < count; s0 += 32768) steps.push_back({l, s0});
     }
-    // the physical REFLECT_101 border of the levels this pass produced (read by the tracker only, never by the pyramid kernels):
-    // one launch; level 0 got its border when the frame was uploaded (dr3hip_batch_upload)
-    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768)
-        HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, align_up(b->win_w + 16, 4), first + s0, count - s0 < 32768 ? count - s0 : 32768, ctx->stream));
-    prof_end(ctx, pe);
+    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768) steps.push_back({-1, s0});
+    ProfEvent pe; prof_open(ctx, DR3HIP_PROF_PYR, pe);
+    for (size_t i = 0; i < steps.size(); ++i) {
+        const int l = steps[i].level, s0 = steps[i].s0, n = count - s0 < 32768 ? count - s0 : 32768;
+        LaunchEv ev;
+        if (pe.which >= 0) { if (i == 0) ev.start = pe.e0; if (i + 1 == steps.size()) ev.stop = pe.e1; }
+        if (l < 0) {
+            HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, align_up(b->win_w + 16, 4), first + s0, n, ctx->stream, &ev));
+            continue;
+        }
+        const bool down = l < L, deriv = with_deriv != 0;
+        PyrArgs a;
+        a.src = b->lv[l];
+        a.dst = down ? b->lv[l + 1] : b->lv[l];
+        a.first = first + s0;
+        ProfEvent p0; prof_open(ctx, l == 0 ? DR3HIP_PROF_PYR_L0 : -1, p0, ev.start);          // the level-0 launch on its own
+        if (p0.which >= 0) {
+            if (!ev.start) ev.start = p0.e0;
+            if (ev.stop) { ctx->ev_pool.push_back(p0.e1); p0.e1 = ev.stop; p0.own1 = false; } else ev.stop = p0.e1;
+        }
+        HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream, &ev));
+        prof_close(ctx, p0);
+    }
+    prof_close(ctx, pe);
     return DR3HIP_OK;
 }
 
@@ -1143,8 +1177,10 @@ int dr3hip_batch_track_diag(dr3hip_batch* b, int n_pairs, int first_slot,
     if (L < 0) return L;
     if (n_pairs == 0 || n_pts == 0) return L;
     DeviceGuard g(ctx->device);
-    ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_LK, pe);
+    ProfEvent pe; prof_open(ctx, DR3HIP_PROF_LK, pe);
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {              // grid.y limit
+        LaunchEv ev;
+        if (pe.which >= 0) { if (p0 == 0) ev.start = pe.e0; if (p0 + 32768 >= n_pairs) ev.stop = pe.e1; }
         const int n = n_pairs - p0 < 32768 ? n_pairs - p0 : 32768;
         const size_t off = (size_t)p0 * n_pts;
         a.n_pts = n_pts;
@@ -1155,9 +1191,9 @@ int dr3hip_batch_track_diag(dr3hip_batch* b, int n_pairs, int first_slot,
         a.status = d_status + off; a.err = d_err + off;
         a.iters = d_iters ? d_iters + off * (L + 1) : nullptr;
         a.reason = d_reason ? d_reason + off : nullptr;
-        HIPCHK(ctx, launch_lk_track(a, n, ctx->stream));
+        HIPCHK(ctx, launch_lk_track(a, n, ctx->stream, &ev));
     }
-    prof_end(ctx, pe);
+    prof_close(ctx, pe);
     return L;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -163,10 +164,21 @@ struct HalfArgs {
 };
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
-hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s);
-hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s);
+// Timing events that ride on a kernel dispatch (its own start / end timestamps: no event packets between kernels).  DR3_LAUNCH
+// launches with them when a launcher was handed any, plainly otherwise.
+struct LaunchEv { hipEvent_t start = nullptr, stop = nullptr; };
+#define DR3_LAUNCH(ev, kernel, grid, block, shmem, stream, ...)                                                            \
+    do {                                                                                                                   \
+        if ((ev) && ((ev)->start || (ev)->stop))                                                                           \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (ev)->start, (ev)->stop, 0, __VA_ARGS__);            \
+        else                                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                           \
+    } while (0)
+
+hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev = nullptr);
+hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s, const LaunchEv* ev = nullptr);
 hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s);
-hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s);
+hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const LaunchEv* ev = nullptr);
 // counters over the tracker's outputs: cnt = the unsigned long long fields of dr3hip_lk_counters in declaration order
 hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* reason, const int* iters, int levels,
                            unsigned long long* cnt, hipStream_t s);

@@ -535,7 +535,7 @@ static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
     else { ppw = 1; ni = 2; }
 }
 
-hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
+hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const LaunchEv* ev)
 {
     if (n_pairs <= 0 || a.n_pts <= 0) return hipSuccess;
     if (a.win_w < 3 || a.win_h < 3 || a.win_w > 32 || a.win_h > 32) return hipErrorInvalidValue;
@@ -548,16 +548,16 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s)
     const size_t shmem = (size_t)ppw * rhs * lpd * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
     if (ppw == 4) {
-        if (sq == 15) hipLaunchKernelGGL((lk_trackg_kernel<15, 4, 1>), grid, block, shmem, s, a);
-        else hipLaunchKernelGGL((lk_trackg_kernel<0, 4, 1>), grid, block, shmem, s, a);
+        if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 4, 1>), grid, block, shmem, s, a);
+        else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 4, 1>), grid, block, shmem, s, a);
     } else if (ni == 1) {
-        hipLaunchKernelGGL((lk_trackg_kernel<0, 2, 1>), grid, block, shmem, s, a);
+        DR3_LAUNCH(ev, (lk_trackg_kernel<0, 2, 1>), grid, block, shmem, s, a);
     } else if (ppw == 2) {
-        if (sq == 21) hipLaunchKernelGGL((lk_trackg_kernel<21, 2, 2>), grid, block, shmem, s, a);
-        else hipLaunchKernelGGL((lk_trackg_kernel<0, 2, 2>), grid, block, shmem, s, a);
+        if (sq == 21) DR3_LAUNCH(ev, (lk_trackg_kernel<21, 2, 2>), grid, block, shmem, s, a);
+        else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 2, 2>), grid, block, shmem, s, a);
     } else {
-        if (sq == 30) hipLaunchKernelGGL((lk_trackg_kernel<30, 1, 2>), grid, block, shmem, s, a);
-        else hipLaunchKernelGGL((lk_trackg_kernel<0, 1, 2>), grid, block, shmem, s, a);
+        if (sq == 30) DR3_LAUNCH(ev, (lk_trackg_kernel<30, 1, 2>), grid, block, shmem, s, a);
+        else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 1, 2>), grid, block, shmem, s, a);
     }
     return hipGetLastError();
 }

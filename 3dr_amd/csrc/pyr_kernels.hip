@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void upload_level0_kernel(const uint8_t* __res
 
 }  // namespace
 
-hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s)
+hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s, const LaunchEv* ev)
 {
     if (n_slots <= 0 || n_lv <= 0 || lv[0].pad_x <= 0) return hipSuccess;
     PadArgs a; a.first = first; a.n_lv = n_lv;
@@ -314,7 +314,7 @@ hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int firs
         tasks += (2 * lv[i].pad_y + (lv[i].h + 7) / 8 + 3) & ~3;          // whole workgroups per level: a wave never straddles two
     }
     dim3 block(256), grid(tasks / 4, n_slots);                           // one launch for every padded level
-    hipLaunchKernelGGL(pad_reflect_kernel, grid, block, 0, s, a);
+    DR3_LAUNCH(ev, pad_reflect_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -327,7 +327,7 @@ hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const Level
     return hipGetLastError();
 }
 
-hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool deriv, bool level0, hipStream_t s)
+hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev)
 {
     if (n_slots <= 0 || (!down && !deriv)) return hipSuccess;
     PyrArgs a = a_in;
@@ -337,13 +337,13 @@ hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool de
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y) * (unsigned)n_slots);
     dim3 block(NT);
     if (level0) {
-        if (down && deriv)  hipLaunchKernelGGL((pyr_level_kernel<true, true, 0>),  grid, block, 0, s, a);
-        else if (down)      hipLaunchKernelGGL((pyr_level_kernel<true, false, 0>), grid, block, 0, s, a);
-        else                hipLaunchKernelGGL((pyr_level_kernel<false, true, 0>), grid, block, 0, s, a);
+        if (down && deriv)  DR3_LAUNCH(ev, (pyr_level_kernel<true, true, 0>),  grid, block, 0, s, a);
+        else if (down)      DR3_LAUNCH(ev, (pyr_level_kernel<true, false, 0>), grid, block, 0, s, a);
+        else                DR3_LAUNCH(ev, (pyr_level_kernel<false, true, 0>), grid, block, 0, s, a);
     } else {
-        if (down && deriv)  hipLaunchKernelGGL((pyr_level_kernel<true, true, 1>),  grid, block, 0, s, a);
-        else if (down)      hipLaunchKernelGGL((pyr_level_kernel<true, false, 1>), grid, block, 0, s, a);
-        else                hipLaunchKernelGGL((pyr_level_kernel<false, true, 1>), grid, block, 0, s, a);
+        if (down && deriv)  DR3_LAUNCH(ev, (pyr_level_kernel<true, true, 1>),  grid, block, 0, s, a);
+        else if (down)      DR3_LAUNCH(ev, (pyr_level_kernel<true, false, 1>), grid, block, 0, s, a);
+        else                DR3_LAUNCH(ev, (pyr_level_kernel<false, true, 1>), grid, block, 0, s, a);
     }
     return hipGetLastError();
 }
