@@ -1094,23 +1094,24 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
     if (count == 0) return DR3HIP_OK;
     DeviceGuard g(ctx->device);
     const int L = b->levels - 1;
-    // the launches of the pass: the level kernels (chunks of 32768 slots keep tiles * slots far below 2^31 blocks), then the physical
-    // REFLECT_101 border of the levels this pass produced (read by the tracker only, never by the pyramid kernels): one launch per
-    // chunk; level 0 got its border when the frame was uploaded (dr3hip_batch_upload)
-    struct Step { int level, s0; };                         // level < 0: the border launch
+    // the launches of the pass: the level kernels (chunks of 32768 slots keep tiles * slots far below 2^31 blocks).  The physical
+    // REFLECT_101 border of the levels this pass produces (read by the tracker only, never by the pyramid kernels) rides along: the
+    // launch of level l >= 1 also writes level l's border (level 0 got its when the frame was uploaded, dr3hip_batch_upload).  Only
+    // when the last level has no launch of its own (no derivatives wanted) does its border need one.
+    struct Step { int level, s0; };                         // level < 0: the border launch of the last level
     std::vector<Step> steps;
     for (int l = 0; l <= L; ++l) {
         if (l == L && !with_deriv) continue;
         for (int s0 = 0; s0 < count; s0 += 32768) steps.push_back({l, s0});
     }
-    for (int s0 = 0; s0 < count && L >= 1; s0 += 32768) steps.push_back({-1, s0});
+    for (int s0 = 0; s0 < count && L >= 1 && !with_deriv; s0 += 32768) steps.push_back({-1, s0});
     ProfEvent pe; prof_open(ctx, DR3HIP_PROF_PYR, pe);
     for (size_t i = 0; i < steps.size(); ++i) {
         const int l = steps[i].level, s0 = steps[i].s0, n = count - s0 < 32768 ? count - s0 : 32768;
         LaunchEv ev;
         if (pe.which >= 0) { if (i == 0) ev.start = pe.e0; if (i + 1 == steps.size()) ev.stop = pe.e1; }
         if (l < 0) {
-            HIPCHK(ctx, launch_pad_reflect(&b->lv[1], L, align_up(b->win_w + 16, 4), first + s0, n, ctx->stream, &ev));
+            HIPCHK(ctx, launch_pad_reflect(&b->lv[L], 1, align_up(b->win_w + 16, 4), first + s0, n, ctx->stream, &ev));
             continue;
         }
         const bool down = l < L, deriv = with_deriv != 0;
@@ -1123,7 +1124,7 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             if (!ev.start) ev.start = p0.e0;
             if (ev.stop) { ctx->ev_pool.push_back(p0.e1); p0.e1 = ev.stop; p0.own1 = false; } else ev.stop = p0.e1;
         }
-        HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream, &ev));
+        HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream, &ev, l ? align_up(b->win_w + 16, 4) : 0));
         prof_close(ctx, p0);
     }
     prof_close(ctx, pe);

@@ -32,6 +32,9 @@ struct PyrArgs {
     int first;             // first slot of the launch
     int tiles_x, tiles_y;  // filled by the launcher
     int n_swz;             // slots (multiple of 8) covered by the XCD-aware block map
+    // levels >= 1: the launch also writes the REFLECT_101 border of its own SOURCE level (read by the tracker only) with
+    // pad_blocks extra workgroups per slot behind the tile workgroups (0: none); fill = border columns each side
+    int pad_blocks, pad_fill, n_slots;
 };
 
 struct PadArgs {           // pad_reflect_kernel: the padded levels of one build, one launch
@@ -175,7 +178,8 @@ struct LaunchEv { hipEvent_t start = nullptr, stop = nullptr; };
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                           \
     } while (0)
 
-hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev = nullptr);
+hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev = nullptr,
+                            int pad_fill = 0);      // pad_fill > 0 (levels >= 1): the source level's border rides along
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s, const LaunchEv* ev = nullptr);
 hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const LaunchEv* ev = nullptr);

@@ -38,6 +38,81 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+__device__ __forceinline__ uint32_t border_dword(const uint8_t* __restrict__ srow, int xq, int w)
+{
+    if (xq >= 0 && xq + 3 < w) return *reinterpret_cast<const uint32_t*>(srow + xq);
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, w)] << (8 * k);
+    return v;
+}
+
+// one wave-task of the border of level lv of frame slot (see pad_reflect_kernel below for the task list)
+__device__ __forceinline__ void pad_task(const LevelDev& lv, int fill, int task, int slot, int lane)
+{
+    const int w = lv.w, h = lv.h, n_band = 2 * lv.pad_y;
+    uint8_t* img = lv.img + (long long)slot * lv.step;
+    if (task < n_band) {
+        const int y = task < lv.pad_y ? task - lv.pad_y : h + (task - lv.pad_y);
+        const uint8_t* srow = img + (long long)reflect101(y, h) * lv.pitch;
+        uint8_t* drow = img + (long long)y * lv.pitch;
+        const int wq = (w + 2 * fill + 3) >> 2;                           // dwords of a band row (from x = -fill)
+        for (int q = lane; q < wq; q += 64)
+            *reinterpret_cast<uint32_t*>(drow + (q * 4 - fill)) = border_dword(srow, q * 4 - fill, w);
+        return;
+    }
+    const int y = (task - n_band) * 8 + (lane >> 3);
+    const int c = lane & 7;
+    if (y >= h) return;
+    uint8_t* row = img + (long long)y * lv.pitch;
+    const int r0 = w >> 2;                                                // the dword that holds the last interior bytes (mixed if w % 4)
+    const int rq = ((w + fill + 3) >> 2) - r0;                            // right border dwords incl. that one
+    if ((fill & 15) == 0 && w >= fill + 24) {
+        const int nl = fill >> 4;                                         // 16-byte chunks of the left border
+        if (c < nl) {
+            // dst bytes x0 .. x0+15 (x0 = -fill + 16 c) = src[-x0], src[-x0 - 1], ...: dword j of the chunk is bytes
+            // (s + 4, s + 3, s + 2, s + 1) with s = -x0 - 4 j - 4, i.e. [hi.b0, lo.b3, lo.b2, lo.b1] of the aligned pair at s
+            const int s0 = fill - 16 * c - 16;                            // s of j = 3; multiple of 4
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(row + s0);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(d4, d3, 0x01020304u); o.y = __builtin_amdgcn_perm(d3, d2, 0x01020304u);
+            o.z = __builtin_amdgcn_perm(d2, d1, 0x01020304u); o.w = __builtin_amdgcn_perm(d1, d0, 0x01020304u);
+            *reinterpret_cast<uint4*>(row - fill + 16 * c) = o;
+        } else if (c == nl) {
+            *reinterpret_cast<uint32_t*>(row + 4 * r0) = border_dword(row, 4 * r0, w);        // the mixed dword
+        } else {
+            // pure border dwords xq = 4 (r0 + 1 + 4 m + i): bytes src[a], src[a-1], src[a-2], src[a-3], a = 2w - 2 - xq;
+            // a mod 4 = (2w - 2) mod 4 = e for every one of them, so one selector serves the row: byte k of the result is byte
+            // e - k of the aligned dword A = a >> 2, or byte 4 + e - k of dword A - 1
+            const int m = c - nl - 1, first = 1 + 4 * m;                  // index (from r0) of the chunk's first dword
+            if (first < rq) {
+                const int e = (2 * w - 2) & 3;
+                uint32_t sel = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sel |= (uint32_t)(e - k >= 0 ? 4 + e - k : 4 + e - k) << (8 * k);   // index into {hi = A, lo = A-1}: 4+e-k
+                const int xq = 4 * (r0 + first);
+                const int A = (2 * w - 2 - xq) >> 2;                      // dword of the first result; the chunk needs A-4 .. A
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(row) + (A - 4);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                const uint32_t o0 = __builtin_amdgcn_perm(d4, d3, sel), o1 = __builtin_amdgcn_perm(d3, d2, sel);
+                const uint32_t o2 = __builtin_amdgcn_perm(d2, d1, sel), o3 = __builtin_amdgcn_perm(d1, d0, sel);
+                uint32_t* dq = reinterpret_cast<uint32_t*>(row + xq);
+                const int n = rq - first;                                 // dwords left to write (>= 1)
+                if (n >= 4) { dq[0] = o0; dq[1] = o1; dq[2] = o2; dq[3] = o3; }
+                else { dq[0] = o0; if (n > 1) dq[1] = o1; if (n > 2) dq[2] = o2; }
+            }
+        }
+    } else {
+        // narrow levels / odd fill widths: one dword per step with the general reflection
+        const int lq = fill >> 2;
+        for (int k = c; k < lq + rq; k += 8) {
+            const int xq = k < lq ? k * 4 - fill : (r0 + (k - lq)) * 4;
+            *reinterpret_cast<uint32_t*>(row + xq) = border_dword(row, xq, w);
+        }
+    }
+}
+
 // TAG only separates the symbol of the level-0 launch (the dominant, roofline-graded kernel) from the
 // smaller levels so that rocprofv3 --stats reports it on its own row.
 template <bool DOWN, bool DERIV, int TAG>
@@ -46,6 +121,15 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t tile[LR * LP];
 
     const int tid = threadIdx.x;
+    // The border of the launch's source level (levels >= 1) rides along: the workgroups behind the tiles each run four wave-tasks
+    // of pad_task; they read the level's interior, which the previous launch completed, and write where no tile reads or writes.
+    if (TAG != 0 && a.pad_blocks > 0 && blockIdx.x >= (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.n_slots) {
+        const unsigned r = blockIdx.x - (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.n_slots;
+        const unsigned fz = r / (unsigned)a.pad_blocks, t4 = r - fz * (unsigned)a.pad_blocks;
+        const int task = __builtin_amdgcn_readfirstlane((int)t4 * 4 + (tid >> 6));
+        if (task < 2 * a.src.pad_y + (a.src.h + 7) / 8) pad_task(a.src, a.pad_fill, task, a.first + (int)fz, tid & 63);
+        return;
+    }
     // XCD-aware block -> (frame, tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b
     // and b+8 share an XCD and its private L2).  XCD x walks frames x, x+8, ... tile by tile in raster
     // order, so the halo lines a tile shares with its x/y neighbours are L2 hits instead of being
@@ -196,85 +280,13 @@ __global__ __launch_bounds__(NT) void pyr_level_kernel(const PyrArgs a)
 // gathers, which is what this kernel's time was made of.  Only fill_x columns each side are written (what the tracker can
 // read; level 0 reserves more for alignment).  Reads touch the interior only, writes the border (the mixed dword at the right
 // edge rewrites its interior bytes with themselves).  The derivative border is zero from allocation on.
-__device__ __forceinline__ uint32_t border_dword(const uint8_t* __restrict__ srow, int xq, int w)
-{
-    if (xq >= 0 && xq + 3 < w) return *reinterpret_cast<const uint32_t*>(srow + xq);
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v |= (uint32_t)srow[reflect101(xq + k, w)] << (8 * k);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int task_all = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
     int l = 0;
     while (l + 1 < a.n_lv && task_all >= a.task0[l + 1]) ++l;           // wave-uniform
-    const int task = task_all - a.task0[l];
-    const LevelDev& lv = a.lv[l];
-    const int fill = a.fill_x[l];
-    const int w = lv.w, h = lv.h, n_band = 2 * lv.pad_y;
-    uint8_t* img = lv.img + (long long)(a.first + blockIdx.y) * lv.step;
-    if (task < n_band) {
-        const int y = task < lv.pad_y ? task - lv.pad_y : h + (task - lv.pad_y);
-        const uint8_t* srow = img + (long long)reflect101(y, h) * lv.pitch;
-        uint8_t* drow = img + (long long)y * lv.pitch;
-        const int wq = (w + 2 * fill + 3) >> 2;                           // dwords of a band row (from x = -fill)
-        for (int q = lane; q < wq; q += 64)
-            *reinterpret_cast<uint32_t*>(drow + (q * 4 - fill)) = border_dword(srow, q * 4 - fill, w);
-        return;
-    }
-    const int y = (task - n_band) * 8 + (lane >> 3);
-    const int c = lane & 7;
-    if (y >= h) return;
-    uint8_t* row = img + (long long)y * lv.pitch;
-    const int r0 = w >> 2;                                                // the dword that holds the last interior bytes (mixed if w % 4)
-    const int rq = ((w + fill + 3) >> 2) - r0;                            // right border dwords incl. that one
-    if ((fill & 15) == 0 && w >= fill + 24) {
-        const int nl = fill >> 4;                                         // 16-byte chunks of the left border
-        if (c < nl) {
-            // dst bytes x0 .. x0+15 (x0 = -fill + 16 c) = src[-x0], src[-x0 - 1], ...: dword j of the chunk is bytes
-            // (s + 4, s + 3, s + 2, s + 1) with s = -x0 - 4 j - 4, i.e. [hi.b0, lo.b3, lo.b2, lo.b1] of the aligned pair at s
-            const int s0 = fill - 16 * c - 16;                            // s of j = 3; multiple of 4
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(row + s0);
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-            uint4 o;
-            o.x = __builtin_amdgcn_perm(d4, d3, 0x01020304u); o.y = __builtin_amdgcn_perm(d3, d2, 0x01020304u);
-            o.z = __builtin_amdgcn_perm(d2, d1, 0x01020304u); o.w = __builtin_amdgcn_perm(d1, d0, 0x01020304u);
-            *reinterpret_cast<uint4*>(row - fill + 16 * c) = o;
-        } else if (c == nl) {
-            *reinterpret_cast<uint32_t*>(row + 4 * r0) = border_dword(row, 4 * r0, w);        // the mixed dword
-        } else {
-            // pure border dwords xq = 4 (r0 + 1 + 4 m + i): bytes src[a], src[a-1], src[a-2], src[a-3], a = 2w - 2 - xq;
-            // a mod 4 = (2w - 2) mod 4 = e for every one of them, so one selector serves the row: byte k of the result is byte
-            // e - k of the aligned dword A = a >> 2, or byte 4 + e - k of dword A - 1
-            const int m = c - nl - 1, first = 1 + 4 * m;                  // index (from r0) of the chunk's first dword
-            if (first < rq) {
-                const int e = (2 * w - 2) & 3;
-                uint32_t sel = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sel |= (uint32_t)(e - k >= 0 ? 4 + e - k : 4 + e - k) << (8 * k);   // index into {hi = A, lo = A-1}: 4+e-k
-                const int xq = 4 * (r0 + first);
-                const int A = (2 * w - 2 - xq) >> 2;                      // dword of the first result; the chunk needs A-4 .. A
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(row) + (A - 4);
-                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-                const uint32_t o0 = __builtin_amdgcn_perm(d4, d3, sel), o1 = __builtin_amdgcn_perm(d3, d2, sel);
-                const uint32_t o2 = __builtin_amdgcn_perm(d2, d1, sel), o3 = __builtin_amdgcn_perm(d1, d0, sel);
-                uint32_t* dq = reinterpret_cast<uint32_t*>(row + xq);
-                const int n = rq - first;                                 // dwords left to write (>= 1)
-                if (n >= 4) { dq[0] = o0; dq[1] = o1; dq[2] = o2; dq[3] = o3; }
-                else { dq[0] = o0; if (n > 1) dq[1] = o1; if (n > 2) dq[2] = o2; }
-            }
-        }
-    } else {
-        // narrow levels / odd fill widths: one dword per step with the general reflection
-        const int lq = fill >> 2;
-        for (int k = c; k < lq + rq; k += 8) {
-            const int xq = k < lq ? k * 4 - fill : (r0 + (k - lq)) * 4;
-            *reinterpret_cast<uint32_t*>(row + xq) = border_dword(row, xq, w);
-        }
-    }
+    pad_task(a.lv[l], a.fill_x[l], task_all - a.task0[l], a.first + (int)blockIdx.y, lane);
 }
 
 // A frame enters its slot: level 0 is written WITH its REFLECT_101 border -- whole padded rows, full-line stores -- while it is
@@ -327,14 +339,17 @@ hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const Level
     return hipGetLastError();
 }
 
-hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev)
+hipError_t launch_pyr_level(const PyrArgs& a_in, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev, int pad_fill)
 {
     if (n_slots <= 0 || (!down && !deriv)) return hipSuccess;
     PyrArgs a = a_in;
     a.tiles_x = (a.src.w + TW - 1) / TW;
     a.tiles_y = (a.src.h + TH - 1) / TH;
     a.n_swz = n_slots & ~7;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y) * (unsigned)n_slots);
+    a.n_slots = n_slots;
+    a.pad_fill = pad_fill < a.src.pad_x ? pad_fill : a.src.pad_x;
+    a.pad_blocks = (!level0 && pad_fill > 0 && a.src.pad_x > 0) ? (2 * a.src.pad_y + (a.src.h + 7) / 8 + 3) / 4 : 0;
+    dim3 grid(((unsigned)(a.tiles_x * a.tiles_y) + (unsigned)a.pad_blocks) * (unsigned)n_slots);
     dim3 block(NT);
     if (level0) {
         if (down && deriv)  DR3_LAUNCH(ev, (pyr_level_kernel<true, true, 0>),  grid, block, 0, s, a);
