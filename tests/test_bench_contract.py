@@ -80,3 +80,24 @@ def test_live_timing_agrees_with_rocprof_summary_of_the_same_run():
     rows = {r["Name"]: float(r["AverageNs"]) * 1e-6 for r in csv.DictReader(open(stats))}
     all_lk = [v for k, v in rows.items() if d["lk_kernel"]["kernel"] in k]
     assert all_lk and all_lk[0] == pytest.approx(lk[0]["mean_ms_all"], rel=1e-3) and all_lk[0] >= 0.98 * lk[0]["mean_ms_timed"]
+
+
+def test_committed_profiles_were_made_from_the_kernel_sources_in_the_tree():
+    """the counters the bench line quotes (PMC traffic, the tracker's VALU counts and opcode mix) carry the hash of the kernel
+    sources they were collected from; the newest committed set must be that of the sources now in the tree, or the next bench
+    run would report `null` for them (bench.newest_profile)"""
+    import importlib.util
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    spec = importlib.util.spec_from_file_location("summarize_profiles", os.path.join(ROOT, "tools", "summarize_profiles.py"))
+    S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
+    d, path = _newest()
+    prof = os.path.dirname(path)
+    lk = bench.kernel_source_hash(S.LK_HASH_FILES)
+    tr = bench.kernel_source_hash(S.TRAFFIC_HASH_FILES)
+    for f, want in (("pmc_lk.json", lk), ("valu_mix.json", lk), ("pmc_traffic.json", tr), ("pmc_traffic_warp.json", tr)):
+        assert json.load(open(os.path.join(prof, f)))["source_hash"] == want, f
+    assert d["lk_kernel"]["valu_issue"] is not None and d["roofline"]["traffic"] is not None
+    assert os.path.dirname(os.path.join(ROOT, d["roofline"]["traffic_source"])) == prof
