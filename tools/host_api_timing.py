@@ -20,3 +20,10 @@ print("batch.build 2 slots    %.3f ms" % t(lambda: b.build(0, 2, True)))
 P = ctx.to_device(pts.astype(np.float32)); N = ctx.to_device(pts.astype(np.float32)); S = ctx.alloc(2000); E = ctx.alloc(8000)
 print("batch.track 1 pair     %.3f ms" % t(lambda: b.track(1, 0, P, N, 2000, S, E, p)))
 print("d2h 16 KB              %.3f ms" % t(lambda: N.download((2000, 2), np.float32)))
+ctx.profile_enable(True); ctx.profile_reset()
+for _ in range(20): b.track(1, 0, P, N, 2000, S, E, p)
+ms, n = ctx.profile_read(dr3.PROF_LK)
+print("  of which kernel      %.3f ms (dispatch timestamps)" % (ms / n))
+for _ in range(20): b.build(0, 2, True)
+ms, n = ctx.profile_read(dr3.PROF_PYR)
+print("build kernels          %.3f ms (first kernel start to last kernel end)" % (ms / n))
