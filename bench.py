@@ -834,7 +834,39 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
     res["kitti_frames_8uc3"] = kitti_warp_leg(dist, ctx, dr3, synth, sync, tile, steps)
     res["paste"] = paste_leg(dist, ctx, dr3, synth, sync, tile, steps)
     res["stitch"] = stitch_leg(dist, ctx, dr3, synth, sync, tile, steps)
+    res["halfsample"] = halfsample_leg(dist, ctx, dr3, sync, tile, steps)
     return res
+
+
+def halfsample_leg(dist, ctx, dr3, sync, tile, steps):
+    """utils::reduce_to_half (reference src/utils.cpp:382-419, from Frame's create_img_pyramid, src/frame.cpp:18) on a device-resident
+    16000x12000 u8 image (16 copies of the 4000x3000 tile's grey channel), the mode the reference executes on x86-64; 1.25 B per
+    source pixel.  One quadrant against the oracle."""
+    grey = np.ascontiguousarray(tile[..., 1])
+    big = np.tile(grey, (4, 4))
+    h, w = big.shape
+    d_src, d_dst = ctx.to_device(big), ctx.alloc((h // 2) * (w // 2))
+    lib = dr3.lib()
+
+    def run():
+        ctx._chk(lib.dr3hip_halfsample_dev(ctx.h, d_src.ptr, w, h, w, d_dst.ptr, w // 2, dr3.HALF_REF_X86))
+
+    ctx.profile_enable(True)
+    run(); sync(); ctx.profile_reset()
+    timed_region(dist, run, sync, steps, 0)
+    ms, n = ctx.profile_read(dr3.PROF_HALF)
+    ctx.profile_enable(False)
+    k_ms = ms / max(n, 1)
+    ok = None
+    if dist.rank == 0:
+        from oracle import oracle as O
+        got = d_dst.download((h // 2, w // 2), np.uint8)
+        ok = bool(np.array_equal(got[:1500, :2000], O.halfsample(grey, O.HALF_REF_X86)) and np.array_equal(got[:1500, :2000], got[1500:3000, 2000:4000]))
+    nbytes = w * h + (w // 2) * (h // 2)
+    ach = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    return {"image": [w, h], "kernel_ms": k_ms, "verified_vs_oracle": ok,
+            "roofline": {"kernel": "halfsample_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": nbytes}}
 
 
 def kitti_warp_leg(dist, ctx, dr3, synth, sync, tile, steps):
