@@ -20,6 +20,7 @@ port on all host cores and on one thread, bounded sample).  --workload hd runs o
 configs[4] (1920x1080, 5000 corners, 5 levels, 21x21) instead.
 """
 import argparse
+from ctypes import c_float as C_float
 import importlib
 import json
 import os
@@ -835,7 +836,49 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
     res["paste"] = paste_leg(dist, ctx, dr3, synth, sync, tile, steps)
     res["stitch"] = stitch_leg(dist, ctx, dr3, synth, sync, tile, steps)
     res["halfsample"] = halfsample_leg(dist, ctx, dr3, sync, tile, steps)
+    res["remap"] = remap_leg(dist, ctx, dr3, sync, tile, steps)
     return res
+
+
+def remap_leg(dist, ctx, dr3, sync, tile, steps):
+    """cv::remap as utils::warp_local calls it (reference src/utils.cpp:191) on one device-resident 4000x3000 8UC3 tile, twice:
+    driven by the spherical maps read from two f32 planes (row a6: 3 + 8 B read, 3 B written per pixel) and with the maps generated
+    inside the kernel (row f3, utils::warp_spherical, src/utils.cpp:196-201: 3 + 3 B per pixel).  Both against the oracle, whole
+    tile; the two outputs must also be equal to each other."""
+    h, w = tile.shape[:2]
+    f = 0.9 * w
+    lib = dr3.lib()
+    d_src, d_a, d_b = ctx.to_device(tile), ctx.alloc(h * w * 3), ctx.alloc(h * w * 3)
+    out = {}
+    if dist.rank == 0:
+        from oracle import oracle as O
+        u, v = O.spherical_map(w, h, f)
+    else:
+        u = v = np.zeros((h, w), np.float32)
+    d_u, d_v = ctx.to_device(u), ctx.to_device(v)
+    runs = (("maps_from_memory", 14, lambda: ctx._chk(lib.dr3hip_remap_bilinear_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_a.ptr, w, h, 3 * w,
+                                                                                         d_u.ptr, d_v.ptr, 4 * w))),
+            ("spherical_maps_in_kernel", 6, lambda: ctx._chk(lib.dr3hip_warp_local_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_b.ptr, 3 * w,
+                                                                                          dr3.WARP_SPHERICAL, C_float(f)))))
+    for name, bpp, run in runs:
+        ctx.profile_enable(True)
+        run(); sync(); ctx.profile_reset()
+        timed_region(dist, run, sync, steps, 0)
+        ms, n = ctx.profile_read(dr3.PROF_REMAP)
+        ctx.profile_enable(False)
+        k_ms = ms / max(n, 1)
+        ach = bpp * w * h / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out[name] = {"kernel_ms": k_ms, "roofline": {"kernel": "remap_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                                                     "algorithmic_bytes_per_launch": bpp * w * h}}
+    if dist.rank == 0:
+        a, b = d_a.download((h, w, 3), np.uint8), d_b.download((h, w, 3), np.uint8)
+        ref = O.remap(tile, u, v, n_threads=0)
+        out["verified_vs_oracle"] = bool(np.array_equal(a, ref) and np.array_equal(b, ref))
+    else:
+        out["verified_vs_oracle"] = None
+    out["image"] = [w, h]
+    return out
 
 
 def halfsample_leg(dist, ctx, dr3, sync, tile, steps):
