@@ -265,23 +265,57 @@ __global__ __launch_bounds__(64) void check_fundamental_kernel(const CheckFArgs 
 // changing the bits -- so two lanes (x and y) walk the points twice; the shift and scale of the points, which is the bulk of
 // the bytes, runs on all 256 lanes.  With a mask (the tracker's status bytes) lost points are skipped exactly as if they had
 // been erased from the vectors first (:621-635), which is what keeps LK's output on the device up to the inlier vote.
+constexpr int NP_CHUNK = 2048;                     // points staged through LDS per round (coalesced loads by all 256 lanes)
 __global__ __launch_bounds__(256) void normalize_points_kernel(const NormArgs a)
 {
     __shared__ float sh[4];                         // meanX, meanY, sX, sY
+    __shared__ float2 pt[NP_CHUNK];
+    __shared__ uint8_t keep[NP_CHUNK];
     const int t = threadIdx.x;
     const float* __restrict__ xy = a.xy + (long long)blockIdx.x * a.xy_step;
     const uint8_t* __restrict__ mask = a.mask ? a.mask + (long long)blockIdx.x * a.mask_step : nullptr;
     float* __restrict__ out = a.out_xy + (long long)blockIdx.x * a.xy_step;
+    // two sequential passes (the sum, then the absolute deviations from the mean) by lane 0 (x) and lane 1 (y); the points of a
+    // round come out of LDS, where all lanes have put them, instead of one global load per element behind the other
+    float acc = 0.f, mean = 0.f;
+    int N = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        acc = 0.f;
+        for (int c0 = 0; c0 < a.n; c0 += NP_CHUNK) {
+            const int cn = a.n - c0 < NP_CHUNK ? a.n - c0 : NP_CHUNK;
+            __syncthreads();
+            for (int i = t; i < cn; i += 256) {
+                pt[i] = reinterpret_cast<const float2*>(xy)[c0 + i];
+                keep[i] = mask ? mask[c0 + i] : (uint8_t)1;
+            }
+            __syncthreads();
+            if (t < 2) {
+                // masked points add +0.0f (acc is never -0.0f: it starts at +0.0f), so the walk needs no branch and the LDS reads of
+                // eight elements go out ahead of the eight dependent adds
+                const float* v = reinterpret_cast<const float*>(pt) + t;
+                int i = 0;
+                for (; i + 8 <= cn; i += 8) {
+                    float x[8]; uint8_t k[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { x[j] = v[2 * (i + j)]; k[j] = keep[i + j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float term = pass == 0 ? x[j] : fabsf(x[j] - mean);
+                        acc += k[j] ? term : 0.f;
+                        if (pass == 0) N += k[j] ? 1 : 0;
+                    }
+                }
+                for (; i < cn; ++i) {
+                    const float term = pass == 0 ? v[2 * i] : fabsf(v[2 * i] - mean);
+                    acc += keep[i] ? term : 0.f;
+                    if (pass == 0) N += keep[i] ? 1 : 0;
+                }
+            }
+        }
+        if (pass == 0) mean = acc / (float)N;
+    }
     if (t < 2) {
-        float sum = 0.f;
-        int N = 0;
-        for (int i = 0; i < a.n; ++i)
-            if (!mask || mask[i]) { sum += xy[2 * i + t]; ++N; }
-        const float mean = sum / (float)N;
-        float dev = 0.f;
-        for (int i = 0; i < a.n; ++i)
-            if (!mask || mask[i]) dev += fabsf(xy[2 * i + t] - mean);
-        dev = dev / (float)N;
+        const float dev = acc / (float)N;
         sh[t] = mean;
         sh[2 + t] = (float)(1.0 / (double)dev);
     }

@@ -476,6 +476,11 @@ def main(argv=None):
     if args.workload == "kitti" and not args.no_frontend:
         align = align_leg(dist, ctx, dr3, synth, batch, frames, B, (fx, fy, cx, cy), sync, have_gpu, max(3, min(args.steps, 10)))
 
+    # ---- Normalize + the CheckFundamental vote on the tracker's device-resident output -----------------------
+    post_lk = None
+    if args.workload == "kitti" and not args.no_frontend and have_gpu:
+        post_lk = post_lk_leg(dist, ctx, dr3, d_prev, d_next, d_st, pts, N_PTS, sync)
+
     # ---- two sequences per GPU on two streams: the HBM-bound pyramid pass of one overlaps the VALU-bound tracker of the other
     two_streams = None
     if args.workload == "kitti" and not args.no_frontend and have_gpu:
@@ -557,6 +562,7 @@ def main(argv=None):
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,
             "lk_other_windows": lk_other,
+            "post_lk_geometry": post_lk,
             "two_streams": two_streams,
             "sparse_align": align,
             "warp": warp,
@@ -659,6 +665,50 @@ def align_leg(dist, ctx, dr3, synth, batch, frames, B, intr, sync, have_gpu, ste
            "verified_vs_cpu_statement": ok, "note": "extension specified by this build: no reference parity exists"}
     for d in (d_xyz, d_T, d_n, d_c, d_i):
         d.free()
+    return out
+
+
+def post_lk_leg(dist, ctx, dr3, d_prev, d_next, d_st, pts, n_pts, sync):
+    """What the reference does with the tracked points (src/initialization.cpp:80-127, :365-410): InitHelper::Normalize of both
+    point sets and the CheckFundamental vote of 200 RANSAC hypotheses, on pair 0's device-resident tracker output with its status
+    bytes as the mask (nothing leaves the GPU).  Both kernels are sequential f32 sums by definition (a lane per hypothesis / per
+    coordinate walks the matches in order), i.e. latency-bound: reported as time per call, host clock over 50 calls."""
+    rng = np.random.default_rng(5)
+    n_hyp = 200
+    F = (rng.standard_normal((n_hyp, 9)) * np.array([1e-6, 1e-5, 1e-3, 1e-5, 1e-6, 1e-3, 1e-3, 1e-3, 1.0])).astype(np.float32)
+    d_F, d_sc, d_inl = ctx.to_device(F), ctx.alloc(4 * n_hyp), ctx.alloc(n_hyp * n_pts)
+    d_n1, d_n2, d_T = ctx.alloc(8 * n_pts), ctx.alloc(8 * n_pts), ctx.alloc(4 * 9 * 2)
+    out = {"matches": n_pts, "hypotheses": n_hyp}
+
+    def vote():
+        ctx.check_fundamental_dev(d_F, n_hyp, d_prev, d_next, d_st, n_pts, 1.0, d_sc, d_inl)
+
+    def norm():
+        ctx.normalize_points_dev(d_prev, d_st, n_pts, 1, d_n1, d_T)
+        ctx.normalize_points_dev(d_next, d_st, n_pts, 1, d_n2, d_T.ptr + 36)
+
+    for name, fn in (("check_fundamental_ms", vote), ("normalize_two_sets_ms", norm)):
+        fn(); sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            fn()
+        sync()
+        out[name] = (time.perf_counter() - t0) / 50 * 1e3
+    if dist.rank == 0:
+        from oracle import oracle as O
+        p1 = d_prev.download((n_pts, 2), np.float32); p2 = d_next.download((n_pts, 2), np.float32); st = d_st.download((n_pts,), np.uint8)
+        keep = st != 0
+        sc = d_sc.download((n_hyp,), np.float32); inl = d_inl.download((n_hyp, n_pts), np.uint8)
+        ok = True
+        for k in (0, 57, 199):
+            o_sc, o_inl = O.check_fundamental(F[k].reshape(3, 3), p1[keep], p2[keep], 1.0)
+            ok = ok and np.float32(sc[k]).view(np.uint32) == np.float32(o_sc).view(np.uint32) and np.array_equal(inl[k][keep], o_inl)
+        o_n1, o_T1 = O.normalize_points(p1, st)
+        g_n1 = d_n1.download((n_pts, 2), np.float32); g_T = d_T.download((2, 3, 3), np.float32)
+        ok = ok and np.array_equal(g_n1[keep].view(np.uint32), o_n1[keep].view(np.uint32)) and np.array_equal(g_T[0].view(np.uint32), o_T1.view(np.uint32))
+        out["verified_vs_oracle"] = bool(ok)
+    else:
+        out["verified_vs_oracle"] = None
     return out
 
 
