@@ -3,6 +3,7 @@
 // Compiled by hipcc as host code (-ffp-contract=off: the homography inversion below must round
 // like cv::invert does on the reference's x86-64 build).
 #include "dr3hip_internal.h"
+#include "vote.h"
 #include "build_stamp.h"
 #include <algorithm>
 #include <cmath>
@@ -512,7 +513,8 @@ int dr3hip_check_fundamental(dr3hip_ctx* ctx, const float* F21, int n_hyp, const
     a.pts1 = (const float*)dp; a.pts2 = (const float*)(dp + pb); a.n = n;
     a.inv_sigma_square = (float)(1.0 / (double)(sigma * sigma));          // const float invSigmaSquare = 1.0/(sigma*sigma) (:190)
     a.scores = (float*)ctx->stage[3].p; a.inliers = ib ? (uint8_t*)ctx->stage[1].p : nullptr;
-    HIPCHK(ctx, launch_check_fundamental(a, ctx->stream));
+    if ((rc = stage_reserve(ctx, 4, sizeof(float) * vote_scratch_floats(n_hyp, n)))) return rc;
+    HIPCHK(ctx, launch_check_fundamental_2p(a, (float*)ctx->stage[4].p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(scores, a.scores, sb, hipMemcpyDeviceToHost, ctx->stream));
     if (ib && n) HIPCHK(ctx, hipMemcpyAsync(inliers, a.inliers, ib, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -531,7 +533,8 @@ int dr3hip_check_fundamental_dev(dr3hip_ctx* ctx, const float* d_F21, int n_hyp,
     a.pts1 = d_pts1; a.pts2 = d_pts2; a.n = n;
     a.inv_sigma_square = (float)(1.0 / (double)(sigma * sigma));
     a.scores = d_scores; a.inliers = d_inliers;
-    HIPCHK(ctx, launch_check_fundamental(a, ctx->stream));
+    { const int rc = stage_reserve(ctx, 4, sizeof(float) * vote_scratch_floats(n_hyp, n)); if (rc) return rc; }
+    HIPCHK(ctx, launch_check_fundamental_2p(a, (float*)ctx->stage[4].p, ctx->stream));
     return DR3HIP_OK;
 }
 

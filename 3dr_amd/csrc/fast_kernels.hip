@@ -15,6 +15,7 @@
 //                         64-bit atomicMax per grid cell on (score bits, ~raster order): the reference keeps
 //                         the first corner of the best score in level-major raster order.
 #include "dr3hip_internal.h"
+#include "vote.h"
 
 namespace dr3 {
 namespace {
@@ -260,6 +261,78 @@ __global__ __launch_bounds__(64) void check_fundamental_kernel(const CheckFArgs 
     a.scores[hyp] = score;
 }
 
+// ---- the same vote in two phases ------------------------------------------------------------------------------------------
+// The arithmetic of a (match, hypothesis) pair depends on nothing else; only the accumulation of the score is ordered.  Phase 1
+// (vote_chi_kernel) computes both chi-square values of every pair in parallel -- a wave owns 64 hypotheses x 64 matches, lane =
+// hypothesis, the matches of the tile sit one per lane and are broadcast with v_readlane -- and writes them to scratch as
+// chi[match][hypothesis] (512 contiguous bytes per wave-store) plus the inlier bytes (64 contiguous bytes per lane).  Phase 2
+// (vote_sum_kernel), a lane per hypothesis, adds thScore - chi in the reference's order, 64 matches per memory round trip.  An
+// erased match is written as chi = +inf: it fails both tests, which is exactly "contributes nothing, inlier 0".
+typedef uint32_t u32_any __attribute__((aligned(1)));
+__global__ __launch_bounds__(64) void vote_chi_kernel(const CheckFArgs a, float2* __restrict__ chi, int hp, int c0, int cn)
+{
+    const int lane = threadIdx.x;
+    const int hyp_raw = blockIdx.x * 64 + lane;
+    const int hyp = hyp_raw < a.n_hyp ? hyp_raw : a.n_hyp - 1;           // spare lanes shadow the last hypothesis; their columns are padding
+    const float* F = a.F + 9 * hyp;
+    const float f11 = F[0], f12 = F[1], f13 = F[2], f21 = F[3], f22 = F[4], f23 = F[5], f31 = F[6], f32 = F[7], f33 = F[8];
+    const float th = 3.841f, inv = a.inv_sigma_square;
+    const int m0 = blockIdx.y * 64;                                       // first match of the tile, relative to the round
+    const int mi = m0 + lane < cn ? m0 + lane : cn - 1;
+    const float2 p1 = reinterpret_cast<const float2*>(a.pts1)[c0 + mi], p2 = reinterpret_cast<const float2*>(a.pts2)[c0 + mi];
+    const int kept = (m0 + lane < cn) && (!a.mask || a.mask[c0 + mi]);
+    unsigned long long bits = 0ull;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        // the tile's match j, wave-uniform
+        const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1.x), j));
+        const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1.y), j));
+        const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2.x), j));
+        const float v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2.y), j));
+        const int keep = __builtin_amdgcn_readlane(kept, j);
+        const float a2 = f11 * u1 + f12 * v1 + f13, b2 = f21 * u1 + f22 * v1 + f23, c2 = f31 * u1 + f32 * v1 + f33;
+        const float num2 = a2 * u2 + b2 * v2 + c2;
+        float chi1 = num2 * num2 / (a2 * a2 + b2 * b2) * inv;
+        const float a1 = f11 * u2 + f21 * v2 + f31, b1 = f12 * u2 + f22 * v2 + f32, c1 = f13 * u2 + f23 * v2 + f33;
+        const float num1 = a1 * u1 + b1 * v1 + c1;
+        float chi2 = num1 * num1 / (a1 * a1 + b1 * b1) * inv;
+        if (!keep) { chi1 = __builtin_inff(); chi2 = __builtin_inff(); }
+        if (m0 + j < cn) chi[(long long)(m0 + j) * hp + hyp_raw] = make_float2(chi1, chi2);
+        if (!(chi1 > th) && !(chi2 > th)) bits |= 1ull << j;
+    }
+    if (a.inliers && hyp_raw < a.n_hyp) {
+        uint8_t* row = a.inliers + (long long)hyp * a.n + c0 + m0;
+        if (m0 + 64 <= cn) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const uint32_t nib = (uint32_t)(bits >> (4 * d)) & 0xfu;                   // four matches -> four bytes of 0 / 1
+                *reinterpret_cast<u32_any*>(row + 4 * d) = (nib * 0x00204081u) & 0x01010101u;
+            }
+        } else {
+            for (int j = 0; m0 + j < cn; ++j) row[j] = (uint8_t)((bits >> j) & 1ull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void vote_sum_kernel(const CheckFArgs a, const float2* __restrict__ chi, int hp, int cn, int first_round)
+{
+    const int hyp = blockIdx.x * 64 + threadIdx.x;                        // padded columns hold defined values: every lane runs
+    const float th = 3.841f, thScore = 5.991f;
+    float score = (first_round || hyp >= a.n_hyp) ? 0.f : a.scores[hyp];
+    for (int m0 = 0; m0 < cn; m0 += 64) {
+        float2 c[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            c[j] = m0 + j < cn ? chi[(long long)(m0 + j) * hp + hyp] : make_float2(__builtin_inff(), __builtin_inff());
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (!(c[j].x > th)) score += thScore - c[j].x;
+            if (!(c[j].y > th)) score += thScore - c[j].y;
+        }
+    }
+    if (hyp < a.n_hyp) a.scores[hyp] = score;
+}
+
 // InitHelper::Normalize (reference src/initialization.cpp:365-410) for a batch of point sets, one workgroup per set.  The means
 // and the mean absolute deviations are sequential f32 sums in point order -- the one thing that cannot be parallelised without
 // changing the bits -- so two lanes (x and y) walk the points twice; the shift and scale of the points, which is the bulk of
@@ -347,6 +420,26 @@ hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s)
 {
     if (a.n_hyp <= 0) return hipSuccess;
     hipLaunchKernelGGL(check_fundamental_kernel, dim3((a.n_hyp + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+size_t vote_scratch_floats(int n_hyp, int n)
+{
+    const size_t hp = ((size_t)n_hyp + 63) / 64 * 64;
+    return 2 * hp * (size_t)(n < VOTE_CHUNK ? (n > 0 ? n : 1) : VOTE_CHUNK);
+}
+
+hipError_t launch_check_fundamental_2p(const CheckFArgs& a, float* scratch, hipStream_t s)
+{
+    if (a.n_hyp <= 0) return hipSuccess;
+    const int hb = (a.n_hyp + 63) / 64, hp = hb * 64;
+    float2* chi = reinterpret_cast<float2*>(scratch);
+    if (a.n <= 0) { hipLaunchKernelGGL(vote_sum_kernel, dim3(hb), dim3(64), 0, s, a, (const float2*)chi, hp, 0, 1); return hipGetLastError(); }
+    for (int c0 = 0; c0 < a.n; c0 += VOTE_CHUNK) {
+        const int cn = a.n - c0 < VOTE_CHUNK ? a.n - c0 : VOTE_CHUNK;
+        hipLaunchKernelGGL(vote_chi_kernel, dim3(hb, (cn + 63) / 64), dim3(64), 0, s, a, chi, hp, c0, cn);
+        hipLaunchKernelGGL(vote_sum_kernel, dim3(hb), dim3(64), 0, s, a, (const float2*)chi, hp, cn, c0 == 0 ? 1 : 0);
+    }
     return hipGetLastError();
 }
 

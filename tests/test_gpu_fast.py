@@ -132,6 +132,34 @@ def test_normalize_points_bit_exact(dr3, O, ctx):
             d.free()
 
 
+@pytest.mark.parametrize("n, n_hyp", [(1, 1), (63, 5), (64, 64), (65, 70), (1000, 200), (20000, 70)])
+def test_vote_in_two_phases_keeps_the_order_of_the_sum(dr3, O, ctx, n, n_hyp):
+    """the vote runs as a parallel chi-square kernel + an ordered accumulation, in rounds of 16384 matches: partial tiles, hypothesis
+    counts off the wave size, a mask, more matches than one round, non-finite values -- scores and inlier bytes bit for bit"""
+    rng = np.random.default_rng(n * 7 + n_hyp)
+    p1 = np.stack([rng.uniform(0, 1240, n), rng.uniform(0, 375, n)], 1).astype(np.float32)
+    p2 = (p1 + rng.normal(0, 3, (n, 2))).astype(np.float32)
+    if n > 10:
+        p2[3] = np.nan; p1[7, 0] = np.inf
+    Fs = rng.normal(0, 1e-4, (n_hyp, 3, 3)).astype(np.float32); Fs[:, 2, 2] = 1e-2
+    if n_hyp > 2:
+        Fs[2] = 0                                         # 0 / 0 in both chi-squares
+    mask = (rng.random(n) < 0.8).astype(np.uint8)
+    d_F, d_p1, d_p2, d_m = ctx.to_device(Fs), ctx.to_device(p1), ctx.to_device(p2), ctx.to_device(mask)
+    d_sc, d_in = ctx.alloc(4 * n_hyp), ctx.alloc(n_hyp * n)
+    for use_mask in (True, False):
+        ctx.check_fundamental_dev(d_F, n_hyp, d_p1, d_p2, d_m if use_mask else None, n, 1.0, d_sc, d_in)
+        ctx.sync()
+        sc, inl = d_sc.download((n_hyp,), np.float32), d_in.download((n_hyp, n), np.uint8)
+        keep = mask != 0 if use_mask else np.ones(n, bool)
+        for h in sorted({0, n_hyp // 2, n_hyp - 1, min(2, n_hyp - 1)}):
+            with np.errstate(all="ignore"):
+                o_sc, o_in = O.check_fundamental(Fs[h], p1[keep], p2[keep], 1.0)
+            # (a NaN score is a NaN on both sides; x86 and the GPU differ in the sign bit of the default NaN)
+            assert sc[h].view(np.uint32) == np.float32(o_sc).view(np.uint32) or (np.isnan(sc[h]) and np.isnan(o_sc)), (h, sc[h], o_sc)
+            assert np.array_equal(inl[h][keep], o_in) and not inl[h][~keep].any()
+
+
 def test_tracks_stay_on_the_device_up_to_the_inlier_vote(dr3, O, ctx, synth):
     """LK -> Normalize -> CheckFundamental without the points leaving the GPU (SURVEY 8f.4's reason to exist): the tracker's
     device outputs (prev_xy, next_xy, status) feed dr3hip_normalize_points_dev and dr3hip_check_fundamental_dev directly; both
