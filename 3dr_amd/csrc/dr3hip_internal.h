@@ -191,7 +191,6 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
-hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s);
 hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s);
 hipError_t launch_sparse_align(const AlignArgs& a, int n_pairs, hipStream_t s);
 hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);

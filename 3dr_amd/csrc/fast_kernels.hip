@@ -228,40 +228,8 @@ __global__ __launch_bounds__(256) void cells_decode_kernel(const CellsArgs a)
     }
 }
 
-// InitHelper::CheckFundamental (reference src/initialization.cpp:171-249) for all RANSAC hypotheses of
-// FindFundamental (:80-127) at once -- SURVEY 8f.4.  The score is a sequential f32 sum over the matches, so a
-// lane owns one hypothesis and walks the matches in order (every lane of the wave reads the same match: the
-// loads are wave-uniform); the 200 hypotheses of the reference are four waves.  Tiny, kept for residency:
-// tracked points never leave the device between LK and the inlier vote.
-__global__ __launch_bounds__(64) void check_fundamental_kernel(const CheckFArgs a)
-{
-    const int hyp = blockIdx.x * 64 + threadIdx.x;
-    if (hyp >= a.n_hyp) return;
-    const float* F = a.F + 9 * hyp;
-    const float f11 = F[0], f12 = F[1], f13 = F[2], f21 = F[3], f22 = F[4], f23 = F[5], f31 = F[6], f32 = F[7], f33 = F[8];
-    const float th = 3.841f, thScore = 5.991f, inv = a.inv_sigma_square;
-    float score = 0.f;
-    for (int i = 0; i < a.n; ++i) {
-        if (a.mask && !a.mask[i]) {                // erased match (wave-uniform): contributes nothing, as if it were not in the vectors
-            if (a.inliers) a.inliers[(long long)hyp * a.n + i] = 0;
-            continue;
-        }
-        const float u1 = a.pts1[2 * i], v1 = a.pts1[2 * i + 1], u2 = a.pts2[2 * i], v2 = a.pts2[2 * i + 1];
-        bool in = true;
-        const float a2 = f11 * u1 + f12 * v1 + f13, b2 = f21 * u1 + f22 * v1 + f23, c2 = f31 * u1 + f32 * v1 + f33;
-        const float num2 = a2 * u2 + b2 * v2 + c2;
-        const float chi1 = num2 * num2 / (a2 * a2 + b2 * b2) * inv;
-        if (chi1 > th) in = false; else score += thScore - chi1;
-        const float a1 = f11 * u2 + f21 * v2 + f31, b1 = f12 * u2 + f22 * v2 + f32, c1 = f13 * u2 + f23 * v2 + f33;
-        const float num1 = a1 * u1 + b1 * v1 + c1;
-        const float chi2 = num1 * num1 / (a1 * a1 + b1 * b1) * inv;
-        if (chi2 > th) in = false; else score += thScore - chi2;
-        if (a.inliers) a.inliers[(long long)hyp * a.n + i] = in ? 1 : 0;
-    }
-    a.scores[hyp] = score;
-}
-
-// ---- the same vote in two phases ------------------------------------------------------------------------------------------
+// InitHelper::CheckFundamental (reference src/initialization.cpp:171-249) for all RANSAC hypotheses of FindFundamental (:80-127) at
+// once -- SURVEY 8f.4.  Kept on the device for residency: tracked points never leave it between LK and the inlier vote.
 // The arithmetic of a (match, hypothesis) pair depends on nothing else; only the accumulation of the score is ordered.  Phase 1
 // (vote_chi_kernel) computes both chi-square values of every pair in parallel -- a wave owns 64 hypotheses x 64 matches, lane =
 // hypothesis, the matches of the tile sit one per lane and are broadcast with v_readlane -- and writes them to scratch as
@@ -413,13 +381,6 @@ hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s)
 {
     if (a.n_sets <= 0) return hipSuccess;
     hipLaunchKernelGGL(normalize_points_kernel, dim3(a.n_sets), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_check_fundamental(const CheckFArgs& a, hipStream_t s)
-{
-    if (a.n_hyp <= 0) return hipSuccess;
-    hipLaunchKernelGGL(check_fundamental_kernel, dim3((a.n_hyp + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
