@@ -48,6 +48,22 @@ def test_warp_identity_and_integer_translation(dr3, O, ctx):
     assert np.array_equal(ctx.warpPerspective(src, M, (100, 80)), O.warp_perspective(src, M, (100, 80)))
 
 
+def test_warp_pure_translations(dr3, O, ctx):
+    """pure translations (the left image of a stitch, src/stitch.cpp:74): offsets on the 1/64-px ties of the 1/32-px grid, negative,
+    large, barely fractional and tiny ones; forward and inverse maps; every pixel type"""
+    rng = np.random.default_rng(8)
+    offs = [(0.0, 0.0), (5.0, 3.0), (1 / 64, 1 / 64), (-3 / 64, 7 / 64), (-17.515625, 40.984375), (1234.5, -0.25), (2.0 ** -20, 0.0),
+            (1e-12, 3.0), (100.015625, -60.046875), (0.49999997, 0.5000001)]
+    for dtype, shape in ((np.uint8, (61, 83, 3)), (np.uint8, (61, 83)), (np.float32, (33, 45, 4)), (np.uint8, (40, 52, 4))):
+        src = rng.integers(0, 256, shape).astype(dtype)
+        for tx, ty in offs:
+            M = np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float32)
+            for inverse in (False, True):
+                g = ctx.warpPerspective(src, M, (97, 71), flags=dr3.WARP_INVERSE_MAP if inverse else 0)
+                o = O.warp_perspective(src, M, (97, 71), flags=O.WARP_INVERSE_MAP if inverse else 0)
+                assert np.array_equal(g.view(np.uint8), o.view(np.uint8)), (dtype, shape, tx, ty, inverse)
+
+
 def test_warp_rounding_ties_and_fast_path_guard(dr3, O, ctx):
     """source coordinates that land exactly on (or a hair beside) the 1/64-px rounding ties of the 1/32-px
     grid: the kernel's fast coordinate path must hand every such pixel to the exact f64 sequence"""
