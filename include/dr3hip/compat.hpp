@@ -100,6 +100,10 @@ public:
         return c;
     }
     dr3hip_ctx* get() const { return ctx_; }
+    // a caller that runs its own HIP work: enqueue the device-pointer calls on its stream (hipStream_t as void*; nullptr = back to
+    // the context's own stream)
+    void set_stream(void* hip_stream) { check(dr3hip_set_stream(ctx_, hip_stream), "dr3hip_set_stream"); }
+    void* stream() const { return dr3hip_stream(ctx_); }
     int check(int rc, const char* where) const {
         if (rc < 0) throw Error(rc, std::string(where) + ": " + dr3hip_last_error(ctx_));
         return rc;
