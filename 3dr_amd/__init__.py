@@ -157,6 +157,7 @@ def _signatures():
         "dr3hip_lk_stats": ([vp, C.c_longlong, vp, vp, vp, ip, P(LKCounters)], ip),
         "dr3hip_batch_align": ([vp, ip, ip, vp, vp, vp, ip, P(AlignParams), vp, vp, vp, vp], ip),
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
+        "dr3hip_warp_plan": ([P(WarpJob), ip, ip, P(C.c_int), P(C.c_int), P(C.c_int)], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
         "dr3hip_fast_grid_size": ([ip, ip, ip, P(ip), P(ip)], ip),
@@ -640,6 +641,21 @@ def warp_batch(ctx, jobs, img_type, flags=0):
         for k in range(9):
             arr[i].M[k] = float(M[k])
     ctx._chk(lib().dr3hip_warp_perspective_batch(ctx.h, arr, len(jobs), int(img_type), int(flags)))
+
+
+def warp_plan(job, img_type, flags=0):
+    """which kernel dr3hip_warp_perspective_batch runs this job on: dict(kernel=0 direct gather | 2 LDS-staged strips, lds_bytes, tie_guard)"""
+    q = WarpJob()
+    q.src, q.sw, q.sh, q.sstride = job.get("src", 0), job["sw"], job["sh"], job["sstride"]
+    q.dst, q.dw, q.dh, q.dstride = job.get("dst", 0), job["dw"], job["dh"], job["dstride"]
+    M = np.asarray(job["M"], np.float32).reshape(9)
+    for k in range(9):
+        q.M[k] = float(M[k])
+    k, l, g = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().dr3hip_warp_plan(C.byref(q), int(img_type), int(flags), C.byref(k), C.byref(l), C.byref(g))
+    if rc:
+        raise Dr3HipError("dr3hip_warp_plan: %d" % rc)
+    return {"kernel": k.value, "lds_bytes": l.value, "tie_guard": g.value}
 
 
 def panorama_bbox(M, w, h):

@@ -6,6 +6,7 @@
 #include "vote.h"
 #include "build_stamp.h"
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <dlfcn.h>
 
@@ -1413,6 +1414,66 @@ static bool warp_delta_coords_ok(const double M[9], int dw, int dh)
     return q <= 1.2e-4 && dxdx <= 2.0 && dydx <= 2.0;
 }
 
+// May the tile kernel derive the 16 pixels of a lane's destination column from ONE f64 anchor at its centre (warp_kernels.hip,
+// warp_tile_8uc3_kernel)?  On top of warp_fast_coords_ok: |p| <= 2e-4 (p = M7 / W) and the source moves by at most 2 px per
+// destination pixel along y, over the whole destination (both largest where |W| is smallest; source coordinates are bounded by
+// 8000 px there already).  The kernel's error budget is written for exactly these bounds.
+static bool tile_delta_coords_ok(const double M[9], int dw, int dh)
+{
+    double wmin = INFINITY;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
+        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double p = std::fabs(M[7]) / wmin;
+    const double dxdy = std::fabs(M[1]) / wmin + p * 8000.0, dydy = std::fabs(M[4]) / wmin + p * 8000.0;
+    return p <= 2e-4 && dxdy <= 2.0 && dydy <= 2.0;
+}
+
+// May an 8UC3 job run on the LDS-staged strip kernel (warp_tile_8uc3_kernel), and how much LDS does a wave's 64 x 16 strip need?
+// Rows 16-byte aligned, 32-bit offsets, a power-of-two block split, W of one sign (a strip then maps onto a convex quadrilateral)
+// and a nearly affine map (fast == 3).  The LDS figure is an ESTIMATE: the source boxes (as the kernel forms them: corner taps,
+// one pixel of margin, rows cut to multiples of four pixels) of nine strips -- the destination's corners, edge centres and
+// centre -- plus one row and one chunk of slack; the box of a projective map grows monotonically towards one side, so this is its
+// maximum in practice, and a strip that does need more takes the kernel's slow way out (correct, not timed).  Returns 0 when the
+// job cannot run there.
+static int tile_kernel_lds(const WarpJobDev& j, const double M[9])
+{
+    if (j.fast != 3 || j.bw0_shift < 0) return 0;
+    if ((((uintptr_t)j.src | (uintptr_t)j.sstride) & 15) || j.sstride >= (1 << 24) || j.sh >= (1 << 24) || (long long)j.sstride * j.sh >= (1LL << 31)) return 0;
+    const int tiles_x = (j.dw + kWarpTileW - 1) / kWarpTileW, strips_y = (j.dh + kWarpStripRows - 1) / kWarpStripRows;
+    long long worst = 0;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        const int tx = a == 0 ? 0 : a == 1 ? tiles_x / 2 : tiles_x - 1, sy = b == 0 ? 0 : b == 1 ? strips_y / 2 : strips_y - 1;
+        const int xa = tx * kWarpTileW, xb = std::min(xa + kWarpTileW, j.dw) - 1, ya = sy * kWarpStripRows, yb = std::min(ya + kWarpStripRows, j.dh) - 1;
+        long long x_lo = LLONG_MAX, x_hi = LLONG_MIN, y_lo = LLONG_MAX, y_hi = LLONG_MIN;
+        for (int c = 0; c < 4; ++c) {
+            const double x = (c & 1) ? xb : xa, y = (c & 2) ? yb : ya, w = M[6] * x + M[7] * y + M[8];
+            const long long sx = (long long)std::floor(((M[0] * x + M[1] * y + M[2]) / w) + 1.0 / 64), sy2 = (long long)std::floor(((M[3] * x + M[4] * y + M[5]) / w) + 1.0 / 64);
+            x_lo = std::min(x_lo, sx); x_hi = std::max(x_hi, sx); y_lo = std::min(y_lo, sy2); y_hi = std::max(y_hi, sy2);
+        }
+        x_lo -= 1; x_hi += 2; y_lo -= 1; y_hi += 2;
+        const long long ox = x_lo & ~3LL, cpr = ((x_hi - ox + 4) >> 2) + 1, rows = y_hi - y_lo + 2;
+        if (cpr > 64) return 0;
+        worst = std::max(worst, rows * cpr * 16);
+    }
+    return worst <= (long long)kWarpTileLdsBytes ? (int)worst : 0;
+}
+
+// The tie guard of the strip kernel (units: 2^-13 of 1/32 px): its coordinates come out of f32 arithmetic on offsets of at most
+// T = 7.5 rows x the largest source step per destination row, so they carry the rounding of the step (1 ulp of T), of three fused
+// multiply-adds (half an ulp of T each), the dropped cubic term T (7.5 p)^3 and the conversion to an integer (0.5).  Guard 1 if that
+// stays under 0.95, else 2 (tile_delta_coords_ok bounds it by 1.75).
+static int tile_kernel_guard(const double M[9], int dw, int dh)
+{
+    double wmin = INFINITY;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
+        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double p = std::fabs(M[7]) / wmin;
+    const double step = std::fmax(std::fabs(M[1]) / wmin + p * 8000.0, std::fabs(M[4]) / wmin + p * 8000.0);
+    const double T = 7.5 * step * 262144.0, e = 7.5 * p;
+    const double err = 0.5 + 2.5 * T / 16777216.0 + T * e * e * e;
+    return err < 0.95 ? 1 : 2;
+}
+
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags)
 {
@@ -1428,7 +1489,22 @@ static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride
     j.bw0_shift = -1;
     if (j.bw0 >= dw) j.bw0_shift = 31;                                    // x0 == 0 for every x
     else if (j.bw0 >= 64 && (j.bw0 & (j.bw0 - 1)) == 0) j.bw0_shift = __builtin_ctz((unsigned)j.bw0);
-    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? (warp_delta_coords_ok(Md, dw, dh) ? 2 : 1) : 0;
+    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? (warp_delta_coords_ok(Md, dw, dh) ? (tile_delta_coords_ok(Md, dw, dh) ? 3 : 2) : 1) : 0;
+    j.tile_lds = tile_kernel_lds(j, Md);
+    j.tile_guard = j.tile_lds ? tile_kernel_guard(Md, dw, dh) : 2;
+    j.tile = j.tile_lds ? 2 : 0;
+}
+
+int dr3hip_warp_plan(const dr3hip_warp_job* q, int type, int flags, int* kernel, int* lds_bytes, int* tie_guard)
+{
+    if (!q || type_channels(type) == 0 || !side_ok(q->sw) || !side_ok(q->sh) || !side_ok(q->dw) || !side_ok(q->dh)) return DR3HIP_EINVAL;
+    WarpJobDev j;
+    make_job(j, q->src, q->sw, q->sh, q->sstride, q->dst, q->dw, q->dh, q->dstride, q->M, flags);
+    const bool strip = type == DR3HIP_8UC3 && j.tile == 2;
+    if (kernel) *kernel = strip ? 2 : 0;
+    if (lds_bytes) *lds_bytes = strip ? j.tile_lds : 0;
+    if (tie_guard) *tie_guard = strip ? j.tile_guard : 0;
+    return DR3HIP_OK;
 }
 
 int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs, int type, int flags)
@@ -1440,8 +1516,6 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
     DeviceGuard g(ctx->device);
     const int esz = type_elem_bytes(type);
     std::vector<WarpJobDev> hj(n_jobs);
-    int max_dw = 0, max_dh = 0;
-    bool generic = false;
     for (int i = 0; i < n_jobs; ++i) {
         const dr3hip_warp_job& q = jobs[i];
         if (!q.src || !q.dst || !side_ok(q.sw) || !side_ok(q.sh) || !side_ok(q.dw) || !side_ok(q.dh) || q.sstride < q.sw * esz || q.dstride < q.dw * esz)
@@ -1449,17 +1523,27 @@ int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, 
         if (esz >= 4 && (((uintptr_t)q.src | (uintptr_t)q.dst | (uintptr_t)q.sstride | (uintptr_t)q.dstride) & (uintptr_t)(esz - 1)))
             return fail(ctx, DR3HIP_EINVAL, "warp_batch: job %d pointers/strides must be %d-byte aligned", i, esz);
         make_job(hj[i], q.src, q.sw, q.sh, q.sstride, q.dst, q.dw, q.dh, q.dstride, q.M, flags);
-        if (q.dw > max_dw) max_dw = q.dw;
-        if (q.dh > max_dh) max_dh = q.dh;
-        if (hj[i].bw0_shift < 0) generic = true;
+        if (type != DR3HIP_8UC3) hj[i].tile = 0;
     }
+    // 8UC3: the jobs are grouped by the kernel that takes them (LDS-staged tile kernel in its one-anchor form, with per-row
+    // coordinates, or the direct gather); every group is one launch over its jobs (a job record carries its own pointers)
+    std::stable_sort(hj.begin(), hj.end(), [](const WarpJobDev& a, const WarpJobDev& b) { return a.tile > b.tile; });
     int rc;
     if ((rc = stage_reserve(ctx, 5, sizeof(WarpJobDev) * (size_t)n_jobs))) return rc;
     // pageable source is copied out at enqueue time by hipMemcpyAsync, so hj may die at return
     HIPCHK(ctx, hipMemcpyAsync(ctx->stage[5].p, hj.data(), sizeof(WarpJobDev) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_WARP, pe);
-    HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p, n_jobs, max_dw, max_dh, type, generic, ctx->stream));
+    for (int first = 0; first < n_jobs;) {
+        int last = first, max_dw = 0, max_dh = 0, lds = 0;
+        bool generic = false;
+        for (; last < n_jobs && hj[last].tile == hj[first].tile; ++last) {
+            max_dw = std::max(max_dw, hj[last].dw); max_dh = std::max(max_dh, hj[last].dh); lds = std::max(lds, hj[last].tile_lds);
+            if (hj[last].bw0_shift < 0) generic = true;
+        }
+        HIPCHK(ctx, launch_warp((const WarpJobDev*)ctx->stage[5].p + first, last - first, max_dw, max_dh, type, generic, ctx->stream, hj[first].tile, lds));
+        first = last;
+    }
     prof_end(ctx, pe);
     return DR3HIP_OK;
 }

@@ -71,7 +71,12 @@ struct WarpJobDev {
     int bw0;            // WarpPerspectiveInvoker block width (x0/x1 split)
     int bw0_shift;      // log2(bw0) if bw0 is a power of two >= 64; 31 if one block spans the row; else -1 (generic kernel)
     int fast;           // 1: the guarded fast coordinate path may be used (finite M, source <= 8191 x 8191); 2: also its
-                        // one-reciprocal-per-four-pixels form (nearly affine map: warp_delta_coords_ok)
+                        // one-reciprocal-per-four-pixels form (nearly affine map: warp_delta_coords_ok); 3: also the tile kernel's
+                        // one-anchor-per-column-of-16-pixels form (tile_delta_coords_ok)
+    int tile;           // 8UC3: 0 = direct gather kernel; 2 = LDS-staged tile kernel (fast == 3 and every tile fits the LDS budget)
+    int tile_lds;       // tile != 0: LDS bytes of the largest source box of a wave's strip (tile_kernel_lds; an estimate: a strip
+                        // that needs more takes the kernel's slow way out)
+    int tile_guard;     // tile != 0: the tie guard of the strip kernel in units of 2^-13 of 1/32 px (1 or 2, from the job's error bound)
 };
 
 struct StitchArgs {        // fused Stitch compose (src/stitch.cpp:72-80): job[0] = left (M = T), job[1] = right (M = T * Hinv)
@@ -186,7 +191,12 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
 // counters over the tracker's outputs: cnt = the unsigned long long fields of dr3hip_lk_counters in declaration order
 hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* reason, const int* iters, int levels,
                            unsigned long long* cnt, hipStream_t s);
-hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s);
+// tile_mode (8UC3 only): 0 = direct gather kernel; 2 = LDS-staged tile kernel (jobs with WarpJobDev::tile == 2)
+// tile_lds: LDS bytes of the largest tile source box of the launch's jobs (WarpJobDev::tile_lds)
+hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s, int tile_mode = 0,
+                       int tile_lds = 0);
+constexpr int kWarpTileW = 64, kWarpTileH = 64, kWarpStripRows = 16;   // warp_tile_8uc3_kernel: a workgroup's tile, a wave's strip of it
+constexpr int kWarpTileLdsBytes = 15 * 1024;                          // the largest LDS slice of a wave (4 slices + tie lists <= 64 KiB)
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
 hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);

@@ -12,6 +12,7 @@
 // exact sequence), 15-bit integer weights for 8-bit data (evaluated as perm + dot4), f32 table
 // weights summed left to right without FMA contraction for f32 data.
 #include "dr3hip_internal.h"
+#include <algorithm>
 
 namespace dr3 {
 namespace {
@@ -22,6 +23,8 @@ namespace {
 using gcu8 = const DR3_G uint8_t*;
 using gu8  = DR3_G uint8_t*;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ const DR3_G T* gcast(gcu8 p) { return reinterpret_cast<const DR3_G T*>(p); }
 template <class T> __device__ __forceinline__ DR3_G T* gcast(gu8 p) { return reinterpret_cast<DR3_G T*>(p); }
 
@@ -152,7 +155,7 @@ template <int NPX, bool GENERIC>
 __device__ __forceinline__ void persp_taps(const double* __restrict__ M, int bw0, int bw0_shift, int fast, int x, int y, Tap t[NPX])
 {
 #ifndef DR3_WARP_NO_DELTA
-    if (NPX == 4 && fast == 2) { persp_taps4_delta<GENERIC>(M, bw0, bw0_shift, x, y, t); return; }
+    if (NPX == 4 && fast >= 2) { persp_taps4_delta<GENERIC>(M, bw0, bw0_shift, x, y, t); return; }
 #endif
     // !GENERIC: every job of the launch has a power-of-two block width >= 4 (or one block per row), so
     // the NPX pixels of a lane share the origin and no integer division is compiled in
@@ -444,6 +447,335 @@ __global__ __launch_bounds__(256) void warp_perspective_kernel(const WarpJobDev*
     }
 }
 
+// ==== LDS-staged 8UC3 gather ======================================================================================
+// The one-lane-four-pixels gather above spends two thirds of its instructions outside the blend (f64 coordinates per
+// lane, per-tap interior tests, 24 B fetched through the texture addresser per 3 B used) and sits at a third of HBM
+// peak.  Here ONE WAVE owns a 64 x 16 strip of the destination and a slice of LDS; the four waves of a workgroup (a
+// 64 x 64 tile) never wait for each other, so a CU overlaps the loads of some waves with the arithmetic of others:
+//   1. a lane owns ONE destination column of the strip: one f64 evaluation at the column's centre (the anchor) serves its
+//      16 pixels,
+//          X(j) - X_c = j dX / (1 + j p),   p = M7 / W_c,   1 / (1 + e) ~ 1 - e + e^2,
+//      a cubic in the row offset j = -7.5 .. 7.5 with per-lane f32 coefficients, evaluated in fixed point with 13 extra
+//      fraction bits; a value within 2 units of a rounding tie (1e-3 of the pixels) is recomputed by OpenCV's own f64
+//      sequence, so the taps are bit-identical by construction.  Error budget in those units (|dX/dy|, |dY/dy| <= 2 px/px
+//      and |p| <= 2e-4, bounded by the host, tile_delta_coords_ok): |j dX| < 15 px = 3.9e6 units, so the f32 roundings of the
+//      three fmas and of the coefficients stay under 1.2, the dropped e^3 term under 0.02, the conversion to integer 0.5;
+//   2. W keeps its sign over the destination (job.fast >= 1), so the strip maps onto a convex quadrilateral and the taps of
+//      its four corner pixels (first / last lane, first / last row: v_readlane, scalar min / max), +- 1 px, bound every tap;
+//   3. that source box goes into the wave's LDS slice as one dword per pixel ([B G R x]: 12-byte row loads, three
+//      v_alignbyte and one 16-byte LDS write per four pixels, all loads in flight before the first write), out-of-image
+//      pixels as the border constant 0 -- no per-tap border or interior test is left in the pixel loop, the four taps of a
+//      pixel are two aligned ds_read2_b32, and the 64 lanes read neighbouring dwords (no bank conflicts);
+//   4. the blend is the perm + dot4 sequence of blend8_row2 on the BGRx dwords; the finished pixel dwords [B G R 0] of four
+//      neighbouring lanes are packed into three dwords with one DPP move and one v_perm_b32, so a strip row leaves as
+//      192 contiguous bytes.
+// Jobs whose strips may not fit the LDS slice, whose rows are not 16-byte aligned or whose map is not nearly affine take the
+// direct kernel above (the host groups the jobs of a call by kernel).
+constexpr int kTileW = kWarpTileW, kTileH = kWarpTileH, kWaveRows = kWarpStripRows;
+constexpr int kTileRun = 4;                // x-adjacent tiles that one XCD handles back to back (block -> tile map)
+constexpr int kTieList = 60;               // entries of a wave's list of pixels on a rounding tie (256 B with its padding)
+
+struct TileRegion {                        // wave-uniform
+    int ox, oy;                            // source pixel of region column 0 / row 0 (ox a multiple of 4)
+    int rows, cpr;                         // staged rows, 4-pixel chunks per row
+    int pitch;                             // LDS bytes per row (16 cpr)
+};
+using lds_u32 = const __attribute__((address_space(3))) uint32_t*;
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// BGRx taps: tl, tr of the top row, bl, br of the bottom row -> accumulators, result in byte 2
+__device__ __forceinline__ void blend_taps_bgrx(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, const Blend8& b,
+                                                uint32_t& aB, uint32_t& aG, uint32_t& aR)
+{
+    uint32_t hB0, hG0, hB1, hG1;
+    blend8_row2(__builtin_amdgcn_perm(tr, tl, 0x05010400u), b, hB0, hG0);       // [B0 B1 G0 G1]
+    blend8_row2(__builtin_amdgcn_perm(br, bl, 0x05010400u), b, hB1, hG1);
+    const uint32_t hR0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(tr, tl, 0x0c0c0602u), b.wlo, DR3_HROUND, false);   // [R0 R1 0 0]
+    const uint32_t hR1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(br, bl, 0x0c0c0602u), b.wlo, DR3_HROUND, false);
+    aB = blend8_vert(hB0, hB1, b);
+    aG = blend8_vert(hG0, hG1, b);
+    aR = blend8_vert(hR0, hR1, b);
+}
+
+// The source box of one wave, staged into its LDS slice as BGRx dwords.  CHECKED: the box sticks out of the image (pixels
+// outside are the border constant 0).  Lanes are dealt over (row, chunk) pairs, 64 / cpr rows per pass.  Every load is
+// unconditional -- rows and chunks outside the image or behind the box are clamped onto valid ones and masked afterwards -- so
+// that all loads of a pass are in flight before the first LDS write (a load under a lane condition makes the compiler wait
+// for it at the end of the condition).
+template <bool CHECKED>
+__device__ __forceinline__ void stage_strip_bgrx(const TileRegion& g, gcu8 __restrict__ src, int sw, int sh, int sstride, uint32_t lds0, int lane)
+{
+    constexpr int U = 10;                                                   // row loads in flight per lane and pass
+    // lane -> (row of the pass, chunk): lane / cpr by a 16-bit reciprocal (exact for lane < 64, cpr <= 64)
+    const uint32_t inv = (uint32_t)(65536.0f / (float)g.cpr) + 1u;
+    const int rpp = (int)((64u * inv) >> 16);                               // rows per pass = 64 / cpr
+    const int lr = (int)(((uint32_t)lane * inv) >> 16), c = lane - lr * g.cpr;
+    if (lr >= rpp) return;
+    const int px0 = g.ox + 4 * c;                                           // a multiple of 4
+    uint32_t mk[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    uint32_t ob = 4u, oc = 8u, cb = (uint32_t)(3 * px0);                    // byte offsets of the chunk and of its second / third dword
+    if (CHECKED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mk[i] = (unsigned)(px0 + i) < (unsigned)sw ? 0xffffffffu : 0u;
+        const int rowbytes = 3 * sw;
+        if (!(px0 >= 0 && px0 < sw)) cb = 0u;                               // nothing of the chunk is inside: any valid address, all masked
+        // the chunk that straddles the right edge: a dword whose first byte is valid is read whole (it stays in that byte's page),
+        // the others are replaced by the first one and masked
+        if ((int)cb + 4 >= rowbytes) ob = 0u;
+        if ((int)cb + 8 >= rowbytes) oc = 0u;
+    }
+    const uint32_t lstep = (uint32_t)(rpp * g.pitch), gstep = __umul24((uint32_t)rpp, (uint32_t)sstride);
+    uint32_t loff = lds0 + (uint32_t)(lr * g.pitch + 16 * c);
+    uint32_t goff = cb + (uint32_t)((g.oy + lr) * sstride);                 // !CHECKED: every row of the box is inside the image
+    const int last = g.rows - 1;
+    for (int r0 = lr; r0 <= last; r0 += rpp * U) {
+        uint32_t va[U], vb[U], vc[U], rm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rm[u] = 0xffffffffu;
+            if (!CHECKED) {                                                 // behind the box: the last row again (written twice, same data)
+                const DR3_G uint32_t* q4 = gcast<uint32_t>(src + (r0 + u * rpp <= last ? goff + (uint32_t)u * gstep : cb + (uint32_t)((g.oy + last) * sstride)));
+                va[u] = q4[0]; vb[u] = q4[1]; vc[u] = q4[2];
+            } else {
+                int sy = g.oy + min(r0 + u * rpp, last);
+                rm[u] = (unsigned)sy < (unsigned)sh ? 0xffffffffu : 0u; sy = min(max(sy, 0), sh - 1);
+                gcu8 q = src + (__umul24((uint32_t)sy, (uint32_t)sstride) + cb);
+                va[u] = *gcast<uint32_t>(q); vb[u] = *gcast<uint32_t>(q + ob); vc[u] = *gcast<uint32_t>(q + oc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u32x4 o;
+            o.x = va[u] & mk[0] & rm[u];
+            o.y = __builtin_amdgcn_alignbyte(vb[u], va[u], 3) & mk[1] & rm[u];
+            o.z = __builtin_amdgcn_alignbyte(vc[u], vb[u], 2) & mk[2] & rm[u];
+            o.w = (vc[u] >> 8) & mk[3] & rm[u];
+            const uint32_t la = r0 + u * rpp <= last ? loff + (uint32_t)u * lstep : lds0 + (uint32_t)(last * g.pitch + 16 * c);
+            *(__attribute__((address_space(3))) u32x4*)(uintptr_t)la = o;
+        }
+        loff += U * lstep; goff += U * gstep;
+    }
+}
+
+// One 8UC3 destination column of 16 rows by OpenCV's own sequence and per-tap checked loads: the strip kernel's way out for a
+// strip whose source box does not fit (the host routes such jobs to the direct kernel, so this is a safety net, not a path
+// that is timed).
+__device__ __noinline__ void tile_fallback_8uc3(const WarpJobDev& jb, int x, int y0)
+{
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
+    gcu8 src = (gcu8)jb.src; gu8 dst = (gu8)jb.dst;
+    if (x >= jb.dw) return;
+    const int x0 = block_origin(x, jb.bw0, jb.bw0_shift);
+    for (int j = 0; j < kWaveRows; ++j) {
+        const int y = y0 + j;
+        if (y >= jb.dh) return;
+        const Tap t = persp_tap(M, persp_base(M, x0, y), (double)(x - x0));
+        uint32_t aB = 0u, aG = 0u, aR = 0u;
+        pixel_8uc3(src, jb.sw, jb.sh, jb.sstride, false, t, aB, aG, aR);
+        gu8 o = dst + (long long)y * jb.dstride + (long long)x * 3;
+        o[0] = (uint8_t)byte2(aB); o[1] = (uint8_t)byte2(aG); o[2] = (uint8_t)byte2(aR);
+    }
+}
+
+// a constant the compiler must keep in a VGPR: on gfx950 a VOP2 instruction with a literal or an SGPR operand issues in 4
+// clocks, with VGPR / inline operands in 2 (profiles/r02_lk/ubench_valu_rate.txt)
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t c) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(c)); return r; }
+
+// One pixel on (or next to) a rounding tie: the guarded f64 evaluation of the direct kernel (reciprocal + Newton step, 13 extra
+// fraction bits of its own) and, where that one cannot decide either, OpenCV's own sequence.  Taps from the staged box when they
+// are inside it (a pixel that sits on a tie may round to the column or row next to the box), else from the image: [B G R 0]
+__device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M, int bw0_shift, const TileRegion& g, uint32_t lds0,
+                                                    gcu8 __restrict__ src, int sw, int sh, int sstride, int x, int y)
+{
+    const int x0 = (x >> bw0_shift) << bw0_shift;
+    const PerspBase pb0 = persp_base(M, x0, y);
+    const double S = 262144.0;
+    PerspFast f; f.X0s = pb0.X0 * S; f.Y0s = pb0.Y0 * S; f.M0s = M[0] * S; f.M3s = M[3] * S;
+    Tap e;
+    if (!persp_tap_fast(M, pb0, f, (double)(x - x0), e)) e = persp_tap(M, pb0, (double)(x - x0));
+    const int rx = e.sx - g.ox, ry = e.sy - g.oy;
+    uint32_t aB, aG, aR;
+    if (rx >= 0 && rx + 1 < 4 * g.cpr && ry >= 0 && ry + 1 < g.rows) {
+        const uint32_t addr = lds0 + __umul24((uint32_t)ry, (uint32_t)g.pitch) + 4u * (uint32_t)rx;
+        const lds_u32 pt = (lds_u32)(uintptr_t)addr, pb = (lds_u32)(uintptr_t)(addr + (uint32_t)g.pitch);
+        blend_taps_bgrx(pt[0], pt[1], pb[0], pb[1], blend8_weights(e.fx, e.fy), aB, aG, aR);
+    } else {
+        aB = aG = aR = 0u;
+        pixel_8uc3(src, sw, sh, sstride, false, e, aB, aG, aR);
+    }
+    return __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);
+}
+
+// Every job of the launch: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
+// (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
+__global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* __restrict__ jobs, int tiles_x, int n_tiles, int lds_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const WarpJobDev& jb = jobs[blockIdx.y];
+    // block -> tile: linear block ids b, b + 8 share an XCD (and its L2); an XCD takes kTileRun x-adjacent tiles in a row, so
+    // the 192-byte row segments of neighbouring tiles meet in one L2 before they leave for HBM
+    const int b = blockIdx.x, r = b & (8 * kTileRun - 1);
+    const int t = (b - r) + (r & 7) * kTileRun + (r >> 3);
+    if (t >= n_tiles) return;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int tx0 = tx * kTileW, ty0 = ty * kTileH;
+    const int dw = jb.dw, dh = jb.dh;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int x = tx0 + lane, y0 = ty0 + kWaveRows * wv;
+    const int n_rows = min(kWaveRows, dh - y0);                             // wave-uniform
+    if (tx0 >= dw || n_rows <= 0) return;
+    const int bw0_shift = jb.bw0_shift;
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
+    gcu8 src = (gcu8)jb.src; gu8 dst = (gu8)jb.dst;
+    const int sw = jb.sw, sh = jb.sh, sstride = jb.sstride, dstride = jb.dstride;
+    const bool dst_aligned = ((reinterpret_cast<uintptr_t>(jb.dst) | (uintptr_t)dstride) & 3) == 0;
+    const bool src16 = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)sstride) & 15) == 0 &&
+                       sstride < (1 << 24) && sh < (1 << 24) && (long long)sstride * sh < (1LL << 31);
+    if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { tile_fallback_8uc3(jb, x, y0); return; }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)s_dyn + (uint32_t)wv * (uint32_t)(lds_bytes + 256);    // this wave's slice (LDS byte address)
+    const uint32_t list0 = lds0 + (uint32_t)lds_bytes;
+
+    // anchor: (x, y0 + 7.5), f64; units: 2^-13 of 1/32 px
+    const double xd = (double)x, yd = (double)y0 + 7.5;
+    const double W0 = __builtin_fma(M[6], xd, __builtin_fma(M[7], yd, M[8]));
+    const double NX = __builtin_fma(M[0], xd, __builtin_fma(M[1], yd, M[2]));
+    const double NY = __builtin_fma(M[3], xd, __builtin_fma(M[4], yd, M[5]));
+    double rw = __builtin_amdgcn_rcp(W0);
+    rw = __builtin_fma(__builtin_fma(-W0, rw, 1.0), rw, rw);
+    const double rs = rw * 262144.0;                                          // 32 * 2^13
+    const double X0 = NX * rs, Y0 = NY * rs, pd = M[7] * rw;
+    // X(j) - X_c = j a1 (1 - j p + j^2 p^2): Horner coefficients of the cubic, X and Y side by side (v_pk_fma_f32)
+    const float pf = (float)pd;
+    const f32x2 a1 = {(float)__builtin_fma(-pd, X0, M[1] * rs), (float)__builtin_fma(-pd, Y0, M[4] * rs)};
+    const f32x2 a2 = -a1 * pf, a3 = a1 * (pf * pf);
+    const double X0r = __builtin_rint(X0), Y0r = __builtin_rint(Y0);
+    const f32x2 rem = {(float)(X0 - X0r), (float)(Y0 - Y0r)};
+    // + 4096: round to nearest 1/32 px becomes a floor; + guard: the tie guard's bias (a value whose low 13 bits are < 2 guard is
+    // within `guard` units of a tie; the host sets guard to 1 or 2 from the job's error bound).  The f32 offset (|.| < 2^22) is
+    // rounded to an integer by adding 1.5 * 2^23; the bits of that constant leave with the anchor.
+    const f32x2 magic = {12582912.0f, 12582912.0f};
+    const int guard = jb.tile_guard;
+    const uint32_t g2 = 2u * (uint32_t)guard;
+    const int bX0 = (int)X0r + (4096 + guard) - 0x4B400000, bY0 = (int)Y0r + (4096 + guard) - 0x4B400000;     // absolute
+
+    // the strip's source box from its four corner pixels (convex image of the strip)
+    TileRegion g;
+    {
+        const float ja = -7.5f, jb_ = (float)(n_rows - 1) - 7.5f;
+        const f32x2 jav = {ja, ja}, jbv = {jb_, jb_};
+        const f32x2 da = __builtin_elementwise_fma(jav, __builtin_elementwise_fma(jav, __builtin_elementwise_fma(jav, a3, a2), a1), rem) + magic;
+        const f32x2 db = __builtin_elementwise_fma(jbv, __builtin_elementwise_fma(jbv, __builtin_elementwise_fma(jbv, a3, a2), a1), rem) + magic;
+        const int sxa = (bX0 + (int)__float_as_uint(da.x)) >> 18, sya = (bY0 + (int)__float_as_uint(da.y)) >> 18;
+        const int sxb = (bX0 + (int)__float_as_uint(db.x)) >> 18, syb = (bY0 + (int)__float_as_uint(db.y)) >> 18;
+        const int ll = min(kTileW, dw - tx0) - 1;                           // last lane inside the destination
+        const int x_lo = min(min(__builtin_amdgcn_readlane(sxa, 0), __builtin_amdgcn_readlane(sxb, 0)),
+                             min(__builtin_amdgcn_readlane(sxa, ll), __builtin_amdgcn_readlane(sxb, ll))) - 1;
+        const int x_hi = max(max(__builtin_amdgcn_readlane(sxa, 0), __builtin_amdgcn_readlane(sxb, 0)),
+                             max(__builtin_amdgcn_readlane(sxa, ll), __builtin_amdgcn_readlane(sxb, ll))) + 2;      // right tap + 1
+        const int y_lo = min(min(__builtin_amdgcn_readlane(sya, 0), __builtin_amdgcn_readlane(syb, 0)),
+                             min(__builtin_amdgcn_readlane(sya, ll), __builtin_amdgcn_readlane(syb, ll))) - 1;
+        const int y_hi = max(max(__builtin_amdgcn_readlane(sya, 0), __builtin_amdgcn_readlane(syb, 0)),
+                             max(__builtin_amdgcn_readlane(sya, ll), __builtin_amdgcn_readlane(syb, ll))) + 2;
+        g.ox = x_lo & ~3; g.oy = y_lo;
+        g.rows = y_hi - y_lo + 1;
+        g.cpr = (x_hi - g.ox + 4) >> 2;
+        g.pitch = g.cpr * 16;
+    }
+    if (!(g.cpr >= 1 && g.cpr <= 64 && g.rows >= 1 && g.rows <= 4096 && g.rows * g.pitch <= lds_bytes && g.ox > -16384 && g.oy > -16384)) {
+        tile_fallback_8uc3(jb, x, y0); return;
+    }
+    if (g.ox >= 0 && g.ox + 4 * g.cpr <= sw && g.oy >= 0 && g.oy + g.rows <= sh) stage_strip_bgrx<false>(g, src, sw, sh, sstride, lds0, lane);
+    else                                                                          stage_strip_bgrx<true>(g, src, sw, sh, sstride, lds0, lane);
+    __builtin_amdgcn_wave_barrier();                            // a wave's LDS operations complete in order: no s_barrier
+    const uint32_t pitch = (uint32_t)g.pitch;
+    // region-relative: bits 18.. of aX / aY are the LDS column / row
+    const int aX0 = bX0 - g.ox * 262144, aY0 = bY0 - g.oy * 262144;
+    const uint32_t k8191 = vgpr_const(8191u), k7c0 = vgpr_const(0x7c0u), k800 = vgpr_const(0x800u), k64k = vgpr_const(65536u);
+    const uint32_t kfffc = vgpr_const(0xfffcfffcu);
+    const uint32_t kdot = 1u | ((pitch >> 2) << 16);                        // 4 rx * 1 + 4 ry * (pitch / 4)
+    // output: lanes 4m .. 4m+2 write the three dwords of pixels 4m .. 4m+3
+    const int sub = lane & 3;
+    const uint32_t osel = sub == 0 ? 0x04020100u : sub == 1 ? 0x05040201u : 0x06050402u;
+    const bool quad_ok = dst_aligned && (x | 3) < dw;                       // the whole 4-pixel group exists and rows are dword-aligned
+    const bool st_dword = quad_ok && sub != 3, st_bytes = !quad_ok && x < dw;
+    const uint32_t ooff = quad_ok ? (uint32_t)(4 * (lane - (lane >> 2))) : (uint32_t)(3 * lane);
+    gu8 obase = dst + (long long)y0 * dstride + (long long)tx0 * 3;         // wave-uniform
+    uint32_t own = 0u;                                                      // ties of this lane's column that the list had no room for
+    int n_list = 0;                                                         // wave-uniform
+#pragma unroll
+    for (int j0 = 0; j0 < kWaveRows; j0 += 4) {
+        if (j0 >= n_rows) break;
+        uint32_t nearest = 0xffffffffu;
+        int aX[4], aY[4];
+        uint32_t P[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float oj = (float)(j0 + u) - 7.5f;
+            const f32x2 ojv = {oj, oj};
+            const f32x2 d = __builtin_elementwise_fma(ojv, __builtin_elementwise_fma(ojv, __builtin_elementwise_fma(ojv, a3, a2), a1), rem) + magic;
+            aX[u] = aX0 + (int)__float_as_uint(d.x); aY[u] = aY0 + (int)__float_as_uint(d.y);
+            const uint32_t c = __builtin_amdgcn_perm((uint32_t)aY[u], (uint32_t)aX[u], 0x07060302u) & kfffc;    // [4 rx | 4 ry], fraction bits cleared
+            const uint32_t addr = (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, c), __builtin_bit_cast(s16x2_t, kdot), (int)lds0, false);
+            const lds_u32 pt = (lds_u32)(uintptr_t)addr, pb = (lds_u32)(uintptr_t)(addr + pitch);
+            const uint32_t tl = pt[0], tr = pt[1], bl = pb[0], br = pb[1];
+            nearest = min(nearest, min((uint32_t)aX[u] & k8191, (uint32_t)aY[u] & k8191));
+            Blend8 w;
+            w.wlo = __umul24(__builtin_amdgcn_ubfe((uint32_t)aX[u], 13, 5), 255u) + 32u;
+            w.whi = __umul24(w.wlo, k64k);
+            w.wy1 = ((uint32_t)aY[u] >> 7) & k7c0;
+            w.wy0 = k800 - w.wy1;
+            uint32_t aB, aG, aR;
+            blend_taps_bgrx(tl, tr, bl, br, w, aB, aG, aR);
+            P[u] = __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);           // [B G R 0]
+        }
+        if (__builtin_amdgcn_ballot_w64(nearest < g2)) {                                                                   // rare: note the pixels on a tie in the wave's list
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool tie = (min((uint32_t)aX[u] & 8191u, (uint32_t)aY[u] & 8191u) < g2) && x < dw && j0 + u < n_rows;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(tie);
+                if (tie) {
+                    const int pos = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (pos < kTieList) *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(list0 + 4u * (uint32_t)pos) = ((uint32_t)(j0 + u) << 8) | (uint32_t)lane;
+                    else own |= 1u << (j0 + u);
+                }
+                n_list += __builtin_popcountll(m);
+            }
+        }
+        uint32_t out[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                                          // row_shl:1: the pixel of lane + 1
+            out[u] = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P[u], 0x101, 0xf, 0xf, true), P[u], osel);
+        gu8 orow = obase + (long long)j0 * dstride;
+        if (st_dword) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < n_rows) st_out(gcast<uint32_t>(orow + (long long)u * dstride + ooff), out[u]);
+        } else if (st_bytes) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < n_rows) { gu8 o = orow + (long long)u * dstride + ooff; o[0] = (uint8_t)P[u]; o[1] = (uint8_t)(P[u] >> 8); o[2] = (uint8_t)(P[u] >> 16); }
+        }
+    }
+    // pixels on a rounding tie (1e-3 of them): OpenCV's own sequence, stored over the first result (same wave: its stores to one
+    // address keep their order)
+    n_list = min(n_list, kTieList);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane;;) {
+        int xe, ye;
+        if (i < n_list) { const uint32_t e = *(lds_u32)(uintptr_t)(list0 + 4u * (uint32_t)i); xe = tx0 + (int)(e & 255u); ye = y0 + (int)(e >> 8); i += 64; }
+        else if (own) { xe = x; ye = y0 + __builtin_ctz(own); own &= own - 1u; }
+        else break;
+        const uint32_t v = tile_redo_pixel(M, bw0_shift, g, lds0, src, sw, sh, sstride, xe, ye);
+        gu8 o = dst + (long long)ye * dstride + (long long)xe * 3;
+        o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
+    }
+}
+
 // MAPS = 0: (u, v) read from two f32 planes (cv::remap, reference src/utils.cpp:191).
 // MAPS = 1 / 2: (u, v) generated in the kernel -- utils::compute_spherical_warping / compute_cylindrical_warping
 // (reference src/utils.cpp:125-187, :203-265) fused with warp_local.  The maps are separable up to
@@ -727,11 +1059,25 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
 
 }  // namespace
 
-hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s)
+hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max_dh, int type, bool generic, hipStream_t s, int tile_mode, int tile_lds)
 {
     if (n_jobs <= 0 || max_dw <= 0 || max_dh <= 0) return hipSuccess;
     const int pxt = (type == DR3HIP_8UC1 || type == DR3HIP_8UC3) ? 4 : 1;
     dim3 block(64, 4);
+#ifndef DR3_WARP_NO_TILE
+    if (type == DR3HIP_8UC3 && !generic && tile_mode == 2) {     // LDS-staged 64 x 64 tiles; jobs are grid y
+        const int tiles_x = (max_dw + kTileW - 1) / kTileW;
+        const long long n_tiles = (long long)tiles_x * ((max_dh + kTileH - 1) / kTileH);
+        const int run = 8 * kTileRun;
+        if (n_tiles < (1LL << 30)) {
+            dim3 tgrid((unsigned)((n_tiles + run - 1) / run * run), n_jobs, 1);
+            int lds = (std::max(tile_lds, 1024) + 255) & ~255;               // a wave's slice; behind it the wave's tie list (256 B)
+            if (const char* e = getenv("DR3HIP_TILE_LDS")) lds = atoi(e);      // experiments only
+            hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds);
+            return hipGetLastError();
+        }
+    }
+#endif
     const int tw = pxt == 4 ? WaveTile<4>::LX * 4 : WaveTile<1>::LX, th = 4 * (pxt == 4 ? WaveTile<4>::LY : WaveTile<1>::LY);
     dim3 grid((max_dw + tw - 1) / tw, (max_dh + th - 1) / th, n_jobs);
 #define DR3_WARP_CASE(T) \

@@ -216,6 +216,10 @@ typedef struct dr3hip_warp_job {
 /* Enqueue n_jobs warps of one pixel type in a single launch (job index is a grid axis). */
 int dr3hip_warp_perspective_batch(dr3hip_ctx* ctx, const dr3hip_warp_job* jobs, int n_jobs,
                                   int type, int flags);
+/* Which kernel dr3hip_warp_perspective_batch runs a job on, without running it: *kernel = 0 the direct gather kernel (any type, any
+ * map), 2 the LDS-staged strip kernel (8UC3; rows 16-byte aligned, nearly affine map: DESIGN.md 4.3); *lds_bytes = the LDS slice of a
+ * wave there, *tie_guard = its tie guard (units of 2^-13 of 1/32 px).  Any of the three may be null.  Host only. */
+int dr3hip_warp_plan(const dr3hip_warp_job* job, int type, int flags, int* kernel, int* lds_bytes, int* tie_guard);
 /* Device-pointer remap (maps on device, strides in bytes). */
 int dr3hip_remap_bilinear_dev(dr3hip_ctx* ctx,
                               const void* d_src, int sw, int sh, int sstride, int type,

@@ -230,3 +230,81 @@ def test_warp_batch_heterogeneous_jobs_one_launch(dr3, O, ctx, dtype):
     finally:
         for d in keep:
             d.free()
+
+
+def _near_affine(rng, w, h, angle=0.06, persp=1.5e-5):
+    ang = rng.uniform(-angle, angle)
+    c, s = np.cos(ang), np.sin(ang)
+    sx, sy = rng.uniform(0.93, 1.08, 2)
+    return np.array([[c * sx, -s, rng.uniform(-0.2, 0.2) * w], [s, c * sy, rng.uniform(-0.2, 0.2) * h],
+                     [rng.uniform(-persp, persp), rng.uniform(-persp, persp), 1]], np.float32)
+
+
+def _warp_dev(dr3, ctx, src, M, dsize, spitch=None, dpitch=None, flags=0):
+    """8UC3 warp through dr3hip_warp_perspective_batch with explicit device pitches; returns (result, plan)"""
+    h, w = src.shape[:2]
+    dw, dh = dsize
+    spitch = spitch or (3 * w + 15) // 16 * 16
+    dpitch = dpitch or (3 * dw + 63) // 64 * 64
+    hs = np.zeros((h, spitch), np.uint8); hs[:, :3 * w] = src.reshape(h, 3 * w)
+    d_src, d_dst = ctx.to_device(hs), ctx.to_device(np.full((dh, dpitch), 0xA5, np.uint8))
+    job = dict(src=d_src.ptr, sw=w, sh=h, sstride=spitch, dst=d_dst.ptr, dw=dw, dh=dh, dstride=dpitch, M=M)
+    plan = dr3.warp_plan(job, dr3.T_8UC3, flags)
+    dr3.warp_batch(ctx, [job], dr3.T_8UC3, flags)
+    raw = d_dst.download((dh, dpitch), np.uint8)
+    d_src.free(); d_dst.free()
+    assert (raw[:, 3 * dw:] == 0xA5).all()                      # nothing written behind a destination row
+    return raw[:, :3 * dw].reshape(dh, dw, 3), plan
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (480, 752), (61, 83), (200, 64), (17, 300), (130, 257)])
+def test_strip_kernel_nearly_affine_maps(dr3, O, ctx, shape):
+    """the LDS-staged strip kernel is the one that runs nearly affine 8UC3 jobs: boxes inside the image, boxes that stick out
+    on every side (border constant 0), destinations that end inside a 4-pixel group / a 16-row strip, sources wholly outside"""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    h, w = shape
+    src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    for k in range(8):
+        M = _near_affine(rng, w, h)
+        if k == 6:
+            M[0, 2] += 3.0 * w                                   # the source is nowhere in the destination
+        dsize = (w + (k * 7) % 13, h + (k * 5) % 11) if k % 2 else (max(8, w - 3 * k), max(8, h - 2 * k))
+        got, plan = _warp_dev(dr3, ctx, src, M, dsize)
+        if dsize[1] >= 16:                                       # shorter destinations: OpenCV's block split is not a power of two there
+            assert plan["kernel"] == 2 and plan["tie_guard"] in (1, 2), (k, plan)
+        assert np.array_equal(got, O.warp_perspective(src, M, dsize)), (k, plan)
+        got, plan = _warp_dev(dr3, ctx, src, M, dsize, flags=dr3.WARP_INVERSE_MAP)
+        assert np.array_equal(got, O.warp_perspective(src, M, dsize, O.WARP_INVERSE_MAP)), (k, plan)
+
+
+def test_strip_kernel_store_paths_and_eligibility(dr3, O, ctx):
+    """destination rows that are not dword-aligned take the strip kernel's byte stores; source rows that are not 16-byte aligned and maps
+    that are not nearly affine go to the direct kernel -- same bytes either way"""
+    rng = np.random.default_rng(77)
+    src = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
+    M = _near_affine(rng, 210, 150)
+    want = O.warp_perspective(src, M, (203, 141))
+    got, plan = _warp_dev(dr3, ctx, src, M, (203, 141), dpitch=3 * 203 + 2)         # odd destination pitch
+    assert plan["kernel"] == 2 and np.array_equal(got, want)
+    got, plan = _warp_dev(dr3, ctx, src, M, (203, 141), spitch=3 * 210 + 6)          # 4-byte aligned source rows only
+    assert plan["kernel"] == 0 and np.array_equal(got, want)
+    Mp = M.copy(); Mp[2, 1] = 6e-4                                                   # |M7 / W| above the strip kernel's bound
+    got, plan = _warp_dev(dr3, ctx, src, Mp, (203, 141))
+    assert plan["kernel"] == 0 and np.array_equal(got, O.warp_perspective(src, Mp, (203, 141)))
+    Mz = M.copy(); Mz[0, 0] *= 3.2                                                   # strong minification along x: still one strip per LDS slice?
+    got, plan = _warp_dev(dr3, ctx, src, Mz, (203, 141))
+    assert np.array_equal(got, O.warp_perspective(src, Mz, (203, 141))), plan
+
+
+def test_strip_kernel_every_pixel_on_a_tie(dr3, O, ctx):
+    """translations by k / 64 px and a shear whose columns land on 1/64-px ties: every pixel of every strip goes through the tie list,
+    overflows it and is finished by its own lane"""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (100, 200, 3), dtype=np.uint8)
+    for tx, ty in ((3 / 64, 0.0), (-5 / 64, 9 / 64), (17.515625, -4.984375)):
+        M = np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float32)
+        got, plan = _warp_dev(dr3, ctx, src, M, (200, 100))
+        assert plan["kernel"] == 2 and np.array_equal(got, O.warp_perspective(src, M, (200, 100))), (tx, ty)
+    M = np.array([[1, 1 / 32, 1 / 64], [0, 1, 0.25], [0, 0, 1]], np.float32)            # X moves by 1/32 px per row: a tie on every row
+    got, plan = _warp_dev(dr3, ctx, src, M, (200, 100))
+    assert plan["kernel"] == 2 and np.array_equal(got, O.warp_perspective(src, M, (200, 100)))
