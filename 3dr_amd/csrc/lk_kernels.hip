@@ -106,10 +106,19 @@ __device__ __forceinline__ int dot_s16(uint32_t a, uint32_t b, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, DOT_SAT);
 }
 
+// 8-lane groups: the xor butterfly 1, 2, 4 inside half a DPP row
+__device__ __forceinline__ float half_row_butterfly(float v)
+{
+    v += dpp_xchg<0xB1>(v);     // quad_perm [1,0,3,2]   (xor 1)
+    v += dpp_xchg<0x4E>(v);     // quad_perm [2,3,0,1]   (xor 2)
+    v += dpp_xchg<0x141>(v);    // row_half_mirror       (= xor 4 once quads are uniform)
+    return v;
+}
 // sums over each group of two / three lane values; every lane receives its own group's totals
 template <int PPW>
 __device__ __forceinline__ void group_sum2(float a, float b, float& ra, float& rb)
 {
+    if (PPW == 8) { ra = half_row_butterfly(a); rb = half_row_butterfly(b); return; }
     if (PPW == 4) { ra = row_butterfly(a); rb = row_butterfly(b); return; }
     if (PPW == 1) { wave_sum2(a, b, ra, rb); return; }
     const float v = row_butterfly(fold16(a, b));                 // row totals: a.A  b.A | a.B  b.B
@@ -120,6 +129,7 @@ __device__ __forceinline__ void group_sum2(float a, float b, float& ra, float& r
 template <int PPW>
 __device__ __forceinline__ float group_sum1(float c)
 {
+    if (PPW == 8) return half_row_butterfly(c);
     if (PPW == 4) return row_butterfly(c);
     if (PPW == 1) return wave_sum1(c);
     return row_butterfly(fold16(c, c));
@@ -150,17 +160,23 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef LKG_WAVES_NI2
 #define LKG_WAVES_NI2 4
 #endif
+#ifndef LKG_WAVES_P8
+#define LKG_WAVES_P8 3       // eight points per wave: two 16-tap columns per lane
+#endif
+#ifndef LKG_PPW16
+#define LKG_PPW16 8          // points per wave for windows up to 16 x 16: 8 (two columns per lane) or 4 (one)
+#endif
 // WIN > 0: square compile-time window; WIN = 0: run-time window of the group shape PPW x NI (lk_group_shape below)
 template <int WIN, int PPW, int NI>
 // (the run-time forms holding 16 taps per lane need more registers than four waves per SIMD leave them)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 && NI * (PPW == 4 ? 16 : 8) == 16) ? 3 : (NI == 2 ? LKG_WAVES_NI2 : LKG_WAVES)))) void lk_trackg_kernel(const LKArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (WIN ? LKG_WAVES_P8 : 2) : (WIN == 0 && NI * (PPW == 4 ? 16 : 8) == 16) ? 3 : (NI == 2 ? LKG_WAVES_NI2 : LKG_WAVES)))) void lk_trackg_kernel(const LKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     constexpr int LANES = 64 / PPW;               // lanes per point
-    constexpr int NT = PPW == 4 ? 16 : 8;         // taps (consecutive window rows of one column) per lane-item
-    constexpr int COLS = PPW == 4 ? 8 : 16;       // dword columns of the staging grid (>= the region's width)
+    constexpr int NT = PPW >= 4 ? 16 : 8;         // taps (consecutive window rows of one column) per lane-item
+    constexpr int COLS = PPW >= 4 ? 8 : 16;       // dword columns of the staging grid (>= the region's width)
     constexpr int SR = LANES / COLS;              // rows a group stages per round
-    static_assert(PPW != 4 || NI == 1, "a quarter wave holds one window column per lane");
+    static_assert((PPW != 4 || NI == 1) && (PPW != 8 || NI == 2), "a quarter wave holds one window column per lane, an eighth two");
 
     const int lane = threadIdx.x, hl = lane & (LANES - 1), grp = lane / LANES;
     const int pair = blockIdx.y;
@@ -175,12 +191,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
-    const int nblk = PPW == 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
+    const int nblk = PPW >= 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
     const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd)
     // LDS rows per group: staging runs in rounds of SR rows; the run-time forms also read (and mask) the rows of the taps below the window
-    const int rhs = ((WIN ? rh : PPW == 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
+    const int rhs = ((WIN ? rh : PPW >= 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps_lo = (float)(a.epsilon * (1.0 - 1e-6)), eps_hi = (float)(a.epsilon * (1.0 + 1e-6));
     uint32_t* __restrict__ lds = lds_all + grp * (rhs * lpd);
 
     // lane-item geometry: item q = blk * win_w + c covers the taps (8 blk .. 8 blk + 7, c) -- windows up to 16 x 16: the whole column c --
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     for (int i = 0; i < NI; ++i) {
         const int q = hl + i * LANES;
         const bool ivalid = q < win_w * nblk;
-        const int blk = (PPW == 4 || !ivalid) ? 0 : (q >= win_w) + (q >= 2 * win_w) + (q >= 3 * win_w);
+        const int blk = (PPW >= 4 || !ivalid) ? 0 : (q >= win_w) + (q >= 2 * win_w) + (q >= 3 * win_w);
         itx[i] = ivalid ? q - blk * win_w : 0;
         ity[i] = 8 * blk;
         loffB[i] = (uint32_t)(ity[i] * lpd) * 4u;
@@ -201,12 +218,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
     // item per column the pattern is a constant per h, and the idle lanes are removed from the lane sums instead (lane_mask)
     constexpr bool LANE_MASKED = WIN && PPW == 4;
     const int lane_mask = ntap[0] ? -1 : 0;
-    auto pair_mask = [&ntap](int i, int h) -> uint32_t {
+    // an eighth of a wave with a compile-time window: the pattern is a constant per h as well, but the lane's second column may lie
+    // beyond the window (column 15 of a 15-wide one): its gradients are zeroed through item_mask
+    constexpr bool ITEM_MASKED = WIN && PPW == 8;
+    uint32_t item_mask[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) item_mask[i] = ntap[i] ? 0xffffffffu : 0u;
+    auto pair_mask = [&ntap, &item_mask](int i, int h) -> uint32_t {
         if (LANE_MASKED) return WIN >= 2 * h + 2 ? 0xffffffffu : (WIN == 2 * h + 1 ? 0x0000ffffu : 0u);
+        if (ITEM_MASKED) return (WIN >= 2 * h + 2 ? 0xffffffffu : (WIN == 2 * h + 1 ? 0x0000ffffu : 0u)) & item_mask[i];
         return ntap[i] >= 2 * h + 2 ? 0xffffffffu : (ntap[i] == 2 * h + 1 ? 0x0000ffffu : 0u);
     };
     // a quarter wave with a compile-time window: the taps below the window are not computed at all
-    auto tap_live = [](int k) -> bool { return !(WIN && PPW == 4) || k < WIN; };
+    auto tap_live = [](int k) -> bool { return !(WIN && PPW >= 4) || k < WIN; };
     // staging grid of the group: SR rows x COLS dword columns per round
     const int sc = hl & (COLS - 1), sr = hl / COLS;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;
@@ -416,7 +440,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((WIN == 0 &&
                 const float dy = (A12 * b1 - A11 * b2) * D;
                 cx += dx; cy += dy;
                 nx = cx + half_x; ny = cy + half_y;
-                if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) {
+                // OpenCV tests delta.ddot(delta) <= epsilon in double.  The f32 value of dx^2 + dy^2 is within 3 ulp of that double sum, so
+                // outside [eps_lo, eps_hi] = epsilon (1 -+ 1e-6) it decides the same way; inside, and where the f32 squares may have underflowed,
+                // the double sequence runs
+                const float d2 = dx * dx + dy * dy;
+                bool conv = d2 <= eps_lo;
+                if ((d2 > eps_lo && d2 < eps_hi) || d2 < 1e-30f) conv = (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon;
+                if (conv) {
                     act = false;
                 } else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                     // std::abs(float) < 0.01 (a double) holds exactly for the floats <= 0.01f, the largest float below 0.01
@@ -529,7 +559,7 @@ hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* re
 static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
 {
     const int n8 = win_w * ((win_h + 7) / 8);
-    if (win_w <= 16 && win_h <= 16) { ppw = 4; ni = 1; }
+    if (win_w <= 16 && win_h <= 16) { ppw = LKG_PPW16; ni = LKG_PPW16 == 8 ? 2 : 1; }
     else if (n8 <= 32) { ppw = 2; ni = 1; }
     else if (n8 <= 64) { ppw = 2; ni = 2; }
     else { ppw = 1; ni = 2; }
@@ -541,13 +571,16 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     if (a.win_w < 3 || a.win_h < 3 || a.win_w > 32 || a.win_h > 32) return hipErrorInvalidValue;
     int ppw, ni;
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
-    const int sr = 64 / ppw / (ppw == 4 ? 8 : 16), lpd = ((a.win_w + 15) / 4) | 1;
+    const int sr = 64 / ppw / (ppw >= 4 ? 8 : 16), lpd = ((a.win_w + 15) / 4) | 1;
     const bool fixed = a.win_w == a.win_h && (a.win_w == 15 || a.win_w == 21 || a.win_w == 30);
-    const int rhs = ((fixed ? a.win_h + 9 : ppw == 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;
+    const int rhs = ((fixed ? a.win_h + 9 : ppw >= 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;
     dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
     const size_t shmem = (size_t)ppw * rhs * lpd * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
-    if (ppw == 4) {
+    if (ppw == 8) {
+        if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 8, 2>), grid, block, shmem, s, a);
+        else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 8, 2>), grid, block, shmem, s, a);
+    } else if (ppw == 4) {
         if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 4, 1>), grid, block, shmem, s, a);
         else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 4, 1>), grid, block, shmem, s, a);
     } else if (ni == 1) {

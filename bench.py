@@ -247,7 +247,7 @@ def lk_kernel_of(win_w, win_h):
     lane-items per lane>; WIN = 0 is the run-time-window form."""
     n8 = win_w * ((win_h + 7) // 8)
     if win_w <= 16 and win_h <= 16:
-        ppw, ni, fixed = 4, 1, 15
+        ppw, ni, fixed = 8, 2, 15
     elif n8 <= 32:
         ppw, ni, fixed = 2, 1, -1
     elif n8 <= 64:
@@ -471,6 +471,11 @@ def main(argv=None):
     if args.workload == "kitti" and not args.no_frontend:
         lk_other = lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu)
 
+    # ---- the tracker where flows differ from point to point: the reference's own KITTI pair at the headline launch shape ----------
+    lk_real = None
+    if args.workload == "kitti" and not args.no_frontend:
+        lk_real = lk_real_pair_leg(dist, ctx, dr3, sync, have_gpu)
+
     # ---- SURVEY 8(f) row 5 (extension): sparse image alignment of every consecutive pair of the stream ---------
     align = None
     if args.workload == "kitti" and not args.no_frontend:
@@ -562,6 +567,7 @@ def main(argv=None):
             "host_api_pcie_inclusive": host_api,
             "frontend": frontend,
             "lk_other_windows": lk_other,
+            "lk_real_frames": lk_real,
             "post_lk_geometry": post_lk,
             "two_streams": two_streams,
             "sparse_align": align,
@@ -801,6 +807,81 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
                      "keypoints_per_sec_kernel_only": NP * n / (k_ms * 1e-3), "tracked_fraction": float(d_st.download((NP, n), np.uint8).mean()),
                      "verified_vs_oracle": ok}
         for d in (d_prev, d_next, d_st, d_err):
+            d.free()
+        b.close()
+    return out
+
+
+def lk_real_pair_leg(dist, ctx, dr3, sync, have_gpu):
+    """The tracker on REAL frames whose flows differ from point to point: the reference's own two-view pair (tests/golden/kitti_pair.npz =
+    imgs/kitti0.png / kitti5.png of reference tests/test_init.cpp:24-25, five frames apart on a driving sequence), tiled to the headline
+    launch shape -- 256 pairs in 257 slots A B A B ..., even pairs track A -> B from A's FAST corners, odd pairs B -> A from B's (one
+    corner per 15-px cell, padded to a common count with DR3HIP_NO_POINT) -- at the headline's parameters (15x15, 4 levels, 30 iterations,
+    eps 0.01) and at the reference's call-site literals (src/initialization.cpp:593-613: 30x30, 1000 -> 100 iterations, eps 1e-3,
+    USE_INITIAL_FLOW from the identity).  Reports kernel ms, the mean number of Gauss-Newton iteration-levels per point and the mean
+    over lock-step groups of the slowest point's (what a wave executes), pair 0 against the oracle.  Untimed extra."""
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "kitti_pair.npz")
+    if not have_gpu or not os.path.exists(fix):
+        return None
+    z = np.load(fix)
+    A, Bf = np.ascontiguousarray(z["kitti0"]), np.ascontiguousarray(z["kitti5"])
+    H_, W_ = A.shape
+    NP = 256
+
+    def corners(img):
+        x, y, sc, lv = ctx.fast_detect(img, 3, 15, 20, 20.0)
+        m = lv >= 0
+        return np.stack([x[m], y[m]], 1).astype(np.float32)
+    pa, pb = corners(A), corners(Bf)
+    n = max(len(pa), len(pb))
+    pad = lambda q: np.concatenate([q, np.full((n - len(q), 2), dr3.NO_POINT, np.float32)])
+    pa_, pb_ = pad(pa), pad(pb)
+    P = np.ascontiguousarray(np.stack([pa_ if i % 2 == 0 else pb_ for i in range(NP)]), np.float32)
+    valid = int(sum(len(pa) if i % 2 == 0 else len(pb) for i in range(NP)))
+    out = {"frames": "reference imgs/kitti0.png, kitti5.png (1240x376), %d / %d FAST corners" % (len(pa), len(pb)),
+           "pairs_per_launch": NP, "point_slots_per_pair": n, "valid_points_per_launch": valid}
+    cases = (("headline_15x15", dict(win=(15, 15), max_level=3, max_iters=30, eps=0.01, flags=0)),
+             ("reference_literals_30x30", dict(win=(30, 30), max_level=4, max_iters=1000, eps=1e-3, flags=dr3.LK_USE_INITIAL_FLOW)))
+    for name, kw in cases:
+        b = dr3.FrameBatch(ctx, W_, H_, win=kw["win"], max_level=kw["max_level"], capacity=NP + 1)
+        for s0 in range(0, NP + 1, 64):
+            b.upload(s0, np.stack([A if i % 2 == 0 else Bf for i in range(s0, min(s0 + 64, NP + 1))]))
+        b.build(0, NP + 1, True)
+        lv = b.levels
+        d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+        d_st, d_err, d_it = ctx.alloc(NP * n), ctx.alloc(NP * n * 4), ctx.alloc(NP * n * lv * 4)
+        params = dr3.lk_params(**kw)
+        ctx.profile_enable(True)
+        for _ in range(2):
+            d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params)
+        sync(); ctx.profile_reset()
+        for _ in range(5):
+            d_next.upload(P)                                  # USE_INITIAL_FLOW reads next_xy: every launch starts from the identity guess
+            b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params)
+        sync()
+        ms, cnt = ctx.profile_read(dr3.PROF_LK)
+        ctx.profile_enable(False)
+        d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params, d_iters=d_it); sync()      # untimed: with the iteration counts
+        it = d_it.download((NP, n, lv), np.int32).sum(2)                                                    # iteration-levels per point slot
+        ppw = int(lk_kernel_of(*kw["win"]).split(",")[1])
+        vm = (P[:, :, 0] > -1.0e5)
+        grp = it[:, :n // ppw * ppw].reshape(NP, -1, ppw)
+        grp_live = vm[:, :n // ppw * ppw].reshape(NP, -1, ppw).any(2)                                         # groups that hold a point at all
+        g_xy = d_next.download((NP, n, 2), np.float32); g_st = d_st.download((NP, n), np.uint8)
+        ok = None
+        if dist.rank == 0:
+            from oracle import oracle as O
+            po = O.lk_params(**{**kw, "flags": (O.LK_USE_INITIAL_FLOW if kw["flags"] else 0)})
+            o = O.lk_track(A, Bf, pa, pa.copy() if kw["flags"] else None, po, order=O.ORDER_WAVE64)
+            ok = bool(np.array_equal(g_xy[0, :len(pa)].view(np.uint32), o[0].view(np.uint32)) and np.array_equal(g_st[0, :len(pa)], o[1]))
+        k_ms = ms / max(cnt, 1)
+        out[name] = {"kernel": lk_kernel_of(*kw["win"]), "levels": lv, "kernel_ms": k_ms,
+                     "keypoints_per_sec_kernel_only": valid / (k_ms * 1e-3), "tracked_fraction_of_valid": float(g_st[vm].mean()),
+                     "mean_iteration_levels_per_point": float(it[vm].mean()), "points_per_wave": ppw,
+                     "mean_iteration_levels_of_slowest_in_group": float(grp.max(2)[grp_live].mean()),
+                     "points_at_the_iteration_clamp_frac": float((d_it.download((NP, n, lv), np.int32).max(2)[vm] >= min(kw["max_iters"], 100)).mean()),
+                     "verified_vs_oracle": ok}
+        for d in (d_prev, d_next, d_st, d_err, d_it):
             d.free()
         b.close()
     return out

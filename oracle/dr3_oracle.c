@@ -161,19 +161,20 @@ static inline int der_at(const lvl_deriv* D, int x, int y, int c)
 typedef struct {
     int   order;
     int   win_w;
-    int   blk_shift, lanes;       /* kernel's order: log2(rows per lane-item) and lanes per point (64, 32 = half or 16 = a quarter of a wave) */
+    int   blk_shift, lanes;       /* kernel's order: log2(rows per lane-item) and lanes per point (64, 32 = half or 8 = an eighth of a wave) */
     long long lane[3][64];        /* up to three simultaneous sums: the lane-local part is an exact integer sum */
     float acc[3];
 } wsum;
 
 /* The HIP tracker (3dr_amd/csrc/lk_kernels.hip) tracks a point with a GROUP of lanes, and a lane owns taps of ONE window column.
- * Windows up to 16 x 16 (e.g. the bench's 15x15): a QUARTER of a wave -- 16 lanes, lane = column, four points per wave64.  Every
+ * Windows up to 16 x 16 (e.g. the bench's 15x15): an EIGHTH of a wave -- 8 lanes, a lane owns the columns c and c + 8 (32 taps, one
+ * exact integer sum), eight points per wave64.  Every
  * other window is cut into lane-items of 8 consecutive rows of a column, item q = (ty / 8) * win_w + tx on lane q % lanes: at most
  * 64 items (e.g. 8x32, 21x21) go to HALF a wave, two points per wave; more (e.g. the reference's 30x30) to a whole wave.
  * DR3O_ORDER_WAVE64 follows whichever applies. */
 static int kernel_points_per_wave(int win_w, int win_h)
 {
-    if (win_w <= 16 && win_h <= 16) return 4;
+    if (win_w <= 16 && win_h <= 16) return 8;           /* an EIGHTH of a wave: 8 lanes, lane = columns c and c + 8 */
     if (win_w * ((win_h + 7) / 8) <= 64) return 2;
     return 1;
 }
@@ -182,7 +183,7 @@ static void wsum_init(wsum* s, int order, int win_w, int win_h)
 {
     const int ppw = kernel_points_per_wave(win_w, win_h);
     s->order = order; s->win_w = win_w;
-    s->blk_shift = ppw == 4 ? 4 : 3;
+    s->blk_shift = ppw >= 4 ? 4 : 3;
     s->lanes = 64 / ppw;
     memset(s->lane, 0, sizeof(s->lane));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
@@ -211,9 +212,9 @@ static float wsum_get(wsum* s, int which)
         int off, l;
         if (s->lanes == 64) for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l] + (float)s->lane[which][l + 32];
         else                for (l = 0; l < 32; ++l) a[l] = (float)s->lane[which][l];
-        if (s->lanes == 16) for (l = 0; l < 16; ++l) c[l] = a[l];
+        if (s->lanes <= 16) for (l = 0; l < 16; ++l) c[l] = a[l];
         else                for (l = 0; l < 16; ++l) c[l] = a[l] + a[l + 16];
-        for (off = 1; off < 16; off <<= 1) {
+        for (off = 1; off < (s->lanes == 8 ? 8 : 16); off <<= 1) {
             for (l = 0; l < 16; ++l) b[l] = c[l] + c[l ^ off];
             memcpy(c, b, sizeof(c));
         }
