@@ -158,6 +158,12 @@ def _signatures():
         "dr3hip_batch_align": ([vp, ip, ip, vp, vp, vp, ip, P(AlignParams), vp, vp, vp, vp], ip),
         "dr3hip_warp_perspective_batch": ([vp, P(WarpJob), ip, ip, ip], ip),
         "dr3hip_warp_plan": ([P(WarpJob), ip, ip, P(C.c_int), P(C.c_int), P(C.c_int)], ip),
+        "dr3hip_batch_upload_async": ([vp, ip, ip, vp, ip, C.c_size_t], ip),
+        "dr3hip_batch_upload_wait": ([vp], ip),
+        "dr3hip_host_alloc": ([vp, C.c_size_t, P(vp)], ip),
+        "dr3hip_host_free": ([vp, vp], ip),
+        "dr3hip_download_async": ([vp, vp, vp, C.c_size_t], ip),
+        "dr3hip_download_wait": ([vp], ip),
         "dr3hip_remap_bilinear_dev": ([vp, vp, ip, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip], ip),
         "dr3hip_halfsample_dev": ([vp, vp, ip, ip, ip, vp, ip, ip], ip),
         "dr3hip_fast_grid_size": ([ip, ip, ip, P(ip), P(ip)], ip),
@@ -467,6 +473,27 @@ class Context:
     def bcast(self, buf, nbytes, root=0):
         self._chk(lib().dr3hip_bcast(self.h, buf.ptr if isinstance(buf, DeviceBuffer) else buf, int(nbytes), int(root)))
 
+    def host_alloc(self, shape, dtype=np.uint8):
+        """a numpy array in pinned host memory (dr3hip_host_alloc); release it with host_free(array)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(lib().dr3hip_host_alloc(self.h, n, C.byref(p)))
+        arr = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {}); self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._chk(lib().dr3hip_host_free(self.h, p))
+
+    def download_async(self, host_arr, dbuf, nbytes=None, offset=0):
+        """device -> host on the download stream, behind everything enqueued on the compute stream so far (dr3hip_download_async)"""
+        self._chk(lib().dr3hip_download_async(self.h, host_arr.ctypes.data, dbuf.ptr + offset, int(nbytes if nbytes is not None else host_arr.nbytes)))
+
+    def download_wait(self):
+        self._chk(lib().dr3hip_download_wait(self.h))
+
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
@@ -583,6 +610,22 @@ class FrameBatch:
         n, h, w = frames.shape
         assert (h, w) == (self.h_px, self.w)
         self.ctx._chk(lib().dr3hip_batch_upload(self.h, first, n, _p(frames), frames.strides[1], frames.strides[0]))
+
+    def pad_level0(self, first, count):
+        """level 0 was written through the device pointers of level_info(): give it its border (dr3hip_batch_pad_level0)"""
+        self.ctx._chk(lib().dr3hip_batch_pad_level0(self.h, int(first), int(count)))
+
+    def upload_async(self, first, frames):
+        """the streaming upload (dr3hip_batch_upload_async): returns at once; frames: (count, h, w) u8, C-contiguous, best in pinned
+        memory (Context.host_alloc)"""
+        frames = np.asarray(frames)
+        if frames.ndim == 2:
+            frames = frames[None]
+        assert frames.dtype == np.uint8 and frames.flags.c_contiguous and frames.shape[1:] == (self.h_px, self.w)
+        self.ctx._chk(lib().dr3hip_batch_upload_async(self.h, int(first), int(frames.shape[0]), frames.ctypes.data, self.w, self.w * self.h_px))
+
+    def upload_wait(self):
+        self.ctx._chk(lib().dr3hip_batch_upload_wait(self.h))
 
     def build(self, first, count, with_deriv=True):
         self.ctx._chk(lib().dr3hip_batch_build(self.h, first, count, int(with_deriv)))

@@ -39,6 +39,17 @@ struct dr3hip_ctx {
     std::vector<hipEvent_t> ev_pool;      // recycled events: no hipEventCreate in the steady state
     void* comm = nullptr;                 // ncclComm_t (RCCL), see "multi-GPU" below
     int comm_world = 0, comm_rank = -1;
+    // streaming transfers (dr3hip_batch_upload_async / dr3hip_download_async): a copy stream per direction and a ring of chunk
+    // buffers -- a device bounce buffer (the frames as the host holds them; the compute stream changes the pitch out of it) and a
+    // pinned host staging buffer (only used for pageable sources) per ring slot
+    struct Xfer {
+        static constexpr int K = 4;
+        hipStream_t up = nullptr, down = nullptr;
+        void* dev[K] = {nullptr}; void* pin[K] = {nullptr}; size_t cap = 0;
+        hipEvent_t copied[K] = {nullptr}, consumed[K] = {nullptr}; bool used[K] = {false};
+        hipEvent_t computed = nullptr;    // marks the point of the compute stream a download waits for
+        int next = 0;
+    } xf;
 };
 
 struct dr3hip_batch {
@@ -221,6 +232,24 @@ int dr3hip_init(int device, dr3hip_ctx** out)
     return DR3HIP_OK;
 }
 
+static void xfer_release(dr3hip_ctx* ctx)
+{
+    dr3hip_ctx::Xfer& x = ctx->xf;
+    if (x.up) (void)hipStreamSynchronize(x.up);
+    if (x.down) (void)hipStreamSynchronize(x.down);
+    for (int i = 0; i < dr3hip_ctx::Xfer::K; ++i) {
+        if (x.dev[i]) (void)hipFree(x.dev[i]);
+        if (x.pin[i]) (void)hipHostFree(x.pin[i]);
+        if (x.copied[i]) (void)hipEventDestroy(x.copied[i]);
+        if (x.consumed[i]) (void)hipEventDestroy(x.consumed[i]);
+        x.dev[i] = x.pin[i] = nullptr; x.copied[i] = x.consumed[i] = nullptr; x.used[i] = false;
+    }
+    if (x.computed) (void)hipEventDestroy(x.computed);
+    if (x.up) (void)hipStreamDestroy(x.up);
+    if (x.down) (void)hipStreamDestroy(x.down);
+    x.computed = nullptr; x.up = x.down = nullptr; x.cap = 0;
+}
+
 void dr3hip_destroy(dr3hip_ctx* ctx)
 {
     if (!ctx) return;
@@ -231,6 +260,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
     (void)dr3hip_comm_destroy(ctx);
     for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
+    xfer_release(ctx);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -253,10 +283,15 @@ int dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return DR3HIP_EINVAL;
     DeviceGuard g(ctx->device);
-    // work already enqueued keeps its order: the old stream is drained (and its timing events read) before the switch
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    prof_drain(ctx);
+    // work already enqueued keeps its order: the old stream is drained (and its timing events read) before the switch.  A caller's
+    // stream must outlive the switch away from it; if it did not (the drain fails), the switch still happens -- a context must not
+    // stay stuck on a dead handle -- and the call reports the failure.
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) (void)hipGetLastError();
+    else prof_drain(ctx);
+    if (e != hipSuccess && ctx->stream == ctx->own_stream) return fail(ctx, DR3HIP_EHIP, "set_stream: draining the context's stream failed: %s", hipGetErrorString(e));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (e != hipSuccess) { ctx->pending.clear(); return fail(ctx, DR3HIP_EHIP, "set_stream: the previous stream could not be drained (%s); switched anyway", hipGetErrorString(e)); }
     return DR3HIP_OK;
 }
 
@@ -1058,9 +1093,145 @@ int dr3hip_batch_upload(dr3hip_batch* b, int first, int count, const uint8_t* fr
     if ((rc = stage_reserve(ctx, 7, bytes + 64))) return rc;
     for (int i = 0; i < count; ++i) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->stage[7].p, frames + (size_t)i * frame_step, bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, launch_upload_level0((const uint8_t*)ctx->stage[7].p, (size_t)stride, v, first + i, align_up(b->win_w + 16, 4), ctx->stream));
+        HIPCHK(ctx, launch_upload_level0((const uint8_t*)ctx->stage[7].p, (size_t)stride, v, first + i, align_up(b->win_w + 16, 4), ctx->stream, 1, 0));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DR3HIP_OK;
+}
+
+// ---- streaming transfers ----------------------------------------------------------------------------------------
+static int xfer_init(dr3hip_ctx* ctx, size_t chunk_bytes)
+{
+    dr3hip_ctx::Xfer& x = ctx->xf;
+    if (!x.up) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&x.up, hipStreamNonBlocking));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&x.down, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&x.computed, hipEventDisableTiming));
+        for (int i = 0; i < dr3hip_ctx::Xfer::K; ++i) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&x.copied[i], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&x.consumed[i], hipEventDisableTiming));
+        }
+    }
+    if (x.cap >= chunk_bytes) return DR3HIP_OK;
+    HIPCHK(ctx, hipStreamSynchronize(x.up));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t cap = chunk_bytes + chunk_bytes / 8 + 4096;
+    for (int i = 0; i < dr3hip_ctx::Xfer::K; ++i) {
+        if (x.dev[i]) (void)hipFree(x.dev[i]);
+        if (x.pin[i]) (void)hipHostFree(x.pin[i]);
+        x.dev[i] = x.pin[i] = nullptr; x.used[i] = false;
+        if (hipMalloc(&x.dev[i], cap) != hipSuccess) { x.dev[i] = nullptr; x.cap = 0; return fail(ctx, DR3HIP_ENOMEM, "hipMalloc(%zu) failed", cap); }
+    }
+    x.cap = cap;
+    return DR3HIP_OK;
+}
+
+static bool host_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+int dr3hip_host_alloc(dr3hip_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(ctx, DR3HIP_ENOMEM, "hipHostMalloc(%zu) failed", bytes); }
+    return DR3HIP_OK;
+}
+int dr3hip_host_free(dr3hip_ctx* ctx, void* p)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!p) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    if (ctx->xf.up) HIPCHK(ctx, hipStreamSynchronize(ctx->xf.up));
+    if (ctx->xf.down) HIPCHK(ctx, hipStreamSynchronize(ctx->xf.down));
+    HIPCHK(ctx, hipHostFree(p));
+    return DR3HIP_OK;
+}
+
+// Frames cross the link in chunks on the context's upload stream while the compute stream works on what it was given before: a
+// chunk lands in a device bounce buffer in the host's layout (one linear copy; frames stored back to back travel as ONE copy),
+// the compute stream waits for that copy's event and writes the slots' level 0 with its border (upload_level0_kernel, one launch
+// per chunk), and the bounce buffer goes back to the ring when that kernel has run.  Nothing here waits on the host except for a
+// ring slot whose previous use has not finished (pageable sources only: they are staged through pinned memory by the calling
+// thread, so they may be reused on return; pinned sources -- dr3hip_host_alloc -- are read by the copy engine until
+// dr3hip_batch_upload_wait).  The slots themselves are only written by the compute stream, in its order: an upload enqueued
+// behind a tracker launch never overtakes it.
+int dr3hip_batch_upload_async(dr3hip_batch* b, int first, int count, const uint8_t* frames, int stride, size_t frame_step)
+{
+    if (!b || !frames || first < 0 || count < 0 || first + count > b->capacity || stride < b->w)
+        return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_upload_async: bad arguments") : DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    if (count == 0) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    const LevelDev& v = b->lv[0];
+    const size_t fbytes = (size_t)stride * (b->h - 1) + b->w;              // what is read of one frame
+    if (count > 1 && frame_step < fbytes) return fail(ctx, DR3HIP_EINVAL, "batch_upload_async: frames overlap");
+    const bool packed = count == 1 || frame_step <= fbytes + 4096;          // back to back: a chunk is one linear copy
+    const size_t dstep = packed ? (count == 1 ? fbytes : frame_step) : (size_t)align_up((long long)fbytes, 256ll);
+    const size_t target = (size_t)8 << 20;
+    const int per_chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, target / dstep));
+    int rc;
+    if ((rc = xfer_init(ctx, (size_t)per_chunk * dstep))) return rc;
+    dr3hip_ctx::Xfer& x = ctx->xf;
+    const bool pinned = host_pinned(frames);
+    for (int done = 0; done < count; done += per_chunk) {
+        const int n = std::min(per_chunk, count - done), r = x.next;
+        x.next = (x.next + 1) % dr3hip_ctx::Xfer::K;
+        const uint8_t* src = frames + (size_t)done * frame_step;
+        const size_t cbytes = (size_t)(n - 1) * dstep + fbytes;
+        if (x.used[r]) HIPCHK(ctx, hipStreamWaitEvent(x.up, x.consumed[r], 0));      // the bounce buffer's previous content has been used
+        const uint8_t* from = src;
+        if (!pinned) {
+            if (!x.pin[r] && hipHostMalloc(&x.pin[r], x.cap, hipHostMallocDefault) != hipSuccess) { x.pin[r] = nullptr; return fail(ctx, DR3HIP_ENOMEM, "hipHostMalloc(%zu) failed", x.cap); }
+            if (x.used[r]) HIPCHK(ctx, hipEventSynchronize(x.copied[r]));            // the staging buffer's previous content has left
+            if (packed) memcpy(x.pin[r], src, cbytes);
+            else for (int i = 0; i < n; ++i) memcpy((uint8_t*)x.pin[r] + (size_t)i * dstep, src + (size_t)i * frame_step, fbytes);
+            from = (const uint8_t*)x.pin[r];
+        }
+        if (packed || !pinned) HIPCHK(ctx, hipMemcpyAsync(x.dev[r], from, cbytes, hipMemcpyHostToDevice, x.up));
+        else for (int i = 0; i < n; ++i)
+            HIPCHK(ctx, hipMemcpyAsync((uint8_t*)x.dev[r] + (size_t)i * dstep, src + (size_t)i * frame_step, fbytes, hipMemcpyHostToDevice, x.up));
+        HIPCHK(ctx, hipEventRecord(x.copied[r], x.up));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, x.copied[r], 0));
+        HIPCHK(ctx, launch_upload_level0((const uint8_t*)x.dev[r], (size_t)stride, v, first + done, align_up(b->win_w + 16, 4), ctx->stream, n, dstep));
+        HIPCHK(ctx, hipEventRecord(x.consumed[r], ctx->stream));
+        x.used[r] = true;
+    }
+    return DR3HIP_OK;
+}
+
+int dr3hip_batch_upload_wait(dr3hip_batch* b)
+{
+    if (!b) return DR3HIP_EINVAL;
+    dr3hip_ctx* ctx = b->ctx;
+    DeviceGuard g(ctx->device);
+    if (ctx->xf.up) HIPCHK(ctx, hipStreamSynchronize(ctx->xf.up));
+    return DR3HIP_OK;
+}
+
+// results leave on the download stream, behind everything the compute stream has been given so far, while it goes on
+int dr3hip_download_async(dr3hip_ctx* ctx, void* host, const void* dev, size_t bytes)
+{
+    if (!ctx || (bytes && (!host || !dev))) return DR3HIP_EINVAL;
+    if (!bytes) return DR3HIP_OK;
+    DeviceGuard g(ctx->device);
+    int rc;
+    if ((rc = xfer_init(ctx, 0))) return rc;
+    dr3hip_ctx::Xfer& x = ctx->xf;
+    HIPCHK(ctx, hipEventRecord(x.computed, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(x.down, x.computed, 0));
+    HIPCHK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, x.down));
+    return DR3HIP_OK;
+}
+int dr3hip_download_wait(dr3hip_ctx* ctx)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    DeviceGuard g(ctx->device);
+    if (ctx->xf.down) HIPCHK(ctx, hipStreamSynchronize(ctx->xf.down));
     return DR3HIP_OK;
 }
 

@@ -186,7 +186,9 @@ struct LaunchEv { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_pyr_level(const PyrArgs& a, int n_slots, bool down, bool deriv, bool level0, hipStream_t s, const LaunchEv* ev = nullptr,
                             int pad_fill = 0);      // pad_fill > 0 (levels >= 1): the source level's border rides along
 hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int first, int n_slots, hipStream_t s, const LaunchEv* ev = nullptr);
-hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s);
+// n_frames frames, frame_step bytes apart in d_src, go to the slots slot, slot + 1, ... (grid z)
+hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s, int n_frames = 1,
+                                size_t frame_step = 0);
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const LaunchEv* ev = nullptr);
 // counters over the tracker's outputs: cnt = the unsigned long long fields of dr3hip_lk_counters in declaration order
 hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* reason, const int* iters, int levels,

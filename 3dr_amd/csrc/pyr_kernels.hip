@@ -292,8 +292,11 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const PadArgs a)
 // A frame enters its slot: level 0 is written WITH its REFLECT_101 border -- whole padded rows, full-line stores -- while it is
 // being written anyway (dr3hip_batch_upload: the host frame has crossed PCIe as one linear copy into a bounce buffer; this kernel
 // is the device-side change of pitch).  pad_reflect_kernel then only serves the levels the pyramid pass produces.
-__global__ __launch_bounds__(256) void upload_level0_kernel(const uint8_t* __restrict__ src, long long spitch, LevelDev lv, int slot, int fill)
+__global__ __launch_bounds__(256) void upload_level0_kernel(const uint8_t* __restrict__ src0, long long spitch, LevelDev lv, int slot0, int fill,
+                                                            long long frame_step)
 {
+    const uint8_t* __restrict__ src = src0 + (long long)blockIdx.z * frame_step;       // grid z: frames of one chunk
+    const int slot = slot0 + (int)blockIdx.z;
     const int y = (int)blockIdx.y - lv.pad_y;                              // padded rows -pad_y .. h + pad_y - 1
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int wq = (lv.w + 2 * fill + 3) >> 2;
@@ -330,12 +333,18 @@ hipError_t launch_pad_reflect(const LevelDev* lv, int n_lv, int fill_x, int firs
     return hipGetLastError();
 }
 
-hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s)
+hipError_t launch_upload_level0(const uint8_t* d_src, size_t spitch, const LevelDev& lv, int slot, int fill_x, hipStream_t s, int n_frames,
+                                size_t frame_step)
 {
+    if (n_frames <= 0) return hipSuccess;
     const int fill = fill_x < lv.pad_x ? fill_x : lv.pad_x;
     const int wq = (lv.w + 2 * fill + 3) / 4;
-    dim3 block(256), grid((wq + 255) / 256, lv.h + 2 * lv.pad_y);
-    hipLaunchKernelGGL(upload_level0_kernel, grid, block, 0, s, d_src, (long long)spitch, lv, slot, fill);
+    for (int f0 = 0; f0 < n_frames; f0 += 32768) {
+        const int n = n_frames - f0 < 32768 ? n_frames - f0 : 32768;
+        dim3 block(256), grid((wq + 255) / 256, lv.h + 2 * lv.pad_y, n);
+        hipLaunchKernelGGL(upload_level0_kernel, grid, block, 0, s, d_src + (size_t)f0 * frame_step, (long long)spitch, lv, slot + f0, fill,
+                           (long long)frame_step);
+    }
     return hipGetLastError();
 }
 

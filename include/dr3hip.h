@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DR3HIP_VERSION 100
+#define DR3HIP_VERSION 101
 
 /* error codes */
 #define DR3HIP_OK        0
@@ -87,7 +87,9 @@ int         dr3hip_sync(dr3hip_ctx* ctx);                    /* wait for the ctx
 void*       dr3hip_stream(dr3hip_ctx* ctx);                  /* the hipStream_t kernels are launched on */
 /* Caller-stream form of every "device" call (SURVEY 8b's _async variants): from now on the context enqueues its kernels, copies
  * and collectives on hip_stream (a hipStream_t of the context's device, owned by the caller); NULL returns to the context's own
- * stream.  Work already enqueued is waited for first, so the order of the caller's calls is kept across the switch. */
+ * stream.  Work already enqueued is waited for first, so the order of the caller's calls is kept across the switch.  The caller's
+ * stream must outlive the next dr3hip_set_stream / dr3hip_destroy; if it was destroyed earlier the switch still takes place (the
+ * context does not stay on a dead handle) and the call returns DR3HIP_EHIP. */
 int         dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream);
 
 /* device memory helpers so that a C/Go/Java caller needs no HIP headers */
@@ -157,6 +159,23 @@ int  dr3hip_batch_level_info(const dr3hip_batch* b, int level, dr3hip_level_info
  * bytes) into slots first..first+count-1 (level 0).  Synchronous. */
 int  dr3hip_batch_upload(dr3hip_batch* b, int first, int count,
                          const uint8_t* frames, int stride, size_t frame_step);
+/* The streaming form, for frames that arrive from the host one batch after the other (the reference receives every frame that way:
+ * src/handler.cpp:31-34, tests/test_pipeline.cpp:71-73).  Returns without waiting: the frames cross the link in chunks on the
+ * context's upload stream -- through a ring of device bounce buffers -- while the compute stream works on what it was given before;
+ * the compute stream picks each chunk up behind an event and writes the slots' level 0 with its border.  The slots are written by
+ * the compute stream only, in its order, so an upload enqueued behind a dr3hip_batch_track never overtakes it.  Frames in pinned
+ * host memory (dr3hip_host_alloc) are read by the copy engine until dr3hip_batch_upload_wait returns; frames in pageable memory
+ * are staged through pinned buffers by the calling thread and may be reused on return. */
+int  dr3hip_batch_upload_async(dr3hip_batch* b, int first, int count,
+                               const uint8_t* frames, int stride, size_t frame_step);
+int  dr3hip_batch_upload_wait(dr3hip_batch* b);
+/* Pinned host memory for dr3hip_batch_upload_async / dr3hip_download_async. */
+int  dr3hip_host_alloc(dr3hip_ctx* ctx, size_t bytes, void** out);
+int  dr3hip_host_free(dr3hip_ctx* ctx, void* p);
+/* Results leave on the context's download stream, behind everything the compute stream has been given so far, while the compute
+ * stream goes on (host: pinned memory for a copy that really is asynchronous).  dr3hip_download_wait: all of them have arrived. */
+int  dr3hip_download_async(dr3hip_ctx* ctx, void* host, const void* dev, size_t bytes);
+int  dr3hip_download_wait(dr3hip_ctx* ctx);
 /* Every level of a slot carries OpenCV's winSize border physically (REFLECT_101 pixels; dr3hip_batch_upload writes level 0's with
  * the frame, dr3hip_batch_build those of the levels it produces).  A caller that writes level-0 pixels into a slot by other means
  * (through the device pointers of dr3hip_batch_level_info) calls this before dr3hip_batch_build / _track.  Enqueued on the stream. */

@@ -46,3 +46,87 @@ def test_set_stream_runs_the_batch_on_the_callers_stream(dr3, O, synth, ctx):
     for a, c in zip(ref, got):
         assert np.array_equal(a.view(np.uint8), c.view(np.uint8))
     assert ref[1].sum() > n                   # the case tracks something
+
+
+def _track_all(dr3, ctx, b, n_fr, P, n, p):
+    d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+    d_st, d_err = ctx.alloc((n_fr - 1) * n), ctx.alloc((n_fr - 1) * n * 4)
+    b.track(n_fr - 1, 0, d_prev, d_next, n, d_st, d_err, p)
+    ctx.sync()
+    out = (d_next.download((n_fr - 1, n, 2), np.float32), d_st.download(((n_fr - 1) * n,), np.uint8), d_err.download(((n_fr - 1) * n,), np.float32))
+    for d in (d_prev, d_next, d_st, d_err):
+        d.free()
+    return out
+
+
+@pytest.mark.parametrize("win", [(15, 15), (21, 21)])
+def test_streaming_upload_and_pad_level0_equal_the_synchronous_upload(dr3, synth, ctx, win):
+    """dr3hip_batch_upload_async (pageable and pinned sources, several ring chunks) and level 0 written through the level_info
+    pointers + dr3hip_batch_pad_level0 leave the slots -- pixels AND borders, which only the tracker reads -- as dr3hip_batch_upload does"""
+    import ctypes as C
+    w, h, n_fr = 333, 207, 41
+    base = [synth.frame_pair(w, h, seed=7 + i)[0] for i in range(5)]
+    frames = np.stack([np.roll(base[i % 5], (i // 5, 2 * (i // 5)), (0, 1)) for i in range(n_fr)])
+    pts = synth.grid_points(w, h, 24, border=4)                    # windows reach into the border
+    n = len(pts)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (n_fr - 1, n, 2)), np.float32)
+    p = dr3.lk_params(win=win, max_level=2, max_iters=30, eps=0.01)
+
+    def fresh():
+        return dr3.FrameBatch(ctx, w, h, win=win, max_level=2, capacity=n_fr)
+    b = fresh(); b.upload(0, frames); b.build(0, n_fr, True)
+    ref = _track_all(dr3, ctx, b, n_fr, P, n, p); b.close()
+    assert ref[1].sum() > n
+
+    pinned = ctx.host_alloc(frames.shape); pinned[...] = frames
+    for src in (frames, pinned):
+        b = fresh(); b.upload_async(0, src); b.build(0, n_fr, True)
+        got = _track_all(dr3, ctx, b, n_fr, P, n, p); b.upload_wait(); b.close()
+        assert all(np.array_equal(a.view(np.uint8), c.view(np.uint8)) for a, c in zip(ref, got))
+    ctx.host_free(pinned)
+
+    b = fresh()
+    li = b.level_info(0)
+    for s in range(n_fr):                                           # the caller's own way of filling level 0: rows at the plane's pitch
+        for y in range(h):
+            ctx._chk(dr3.lib().dr3hip_memcpy_h2d(ctx.h, li.img + s * li.img_slot_step + y * li.img_pitch, frames[s, y].ctypes.data, w))
+    b.pad_level0(0, n_fr); b.build(0, n_fr, True)
+    got = _track_all(dr3, ctx, b, n_fr, P, n, p); b.close()
+    assert all(np.array_equal(a.view(np.uint8), c.view(np.uint8)) for a, c in zip(ref, got))
+
+
+def test_upload_of_the_next_batch_never_overtakes_the_tracker_of_this_one(dr3, synth, ctx):
+    """six batches go through ONE set of slots without a single host wait in between: upload_async -> build -> track -> download_async,
+    each into result buffers of its own.  Every batch must come out as if it had run alone."""
+    w, h, n_fr, rounds = 640, 360, 24, 6
+    base = [synth.frame_pair(w, h, seed=90 + i)[0] for i in range(4)]
+    sets = [np.stack([np.roll(base[(i + r) % 4], (r + i // 4, 3 * r + i), (0, 1)) for i in range(n_fr)]) for r in range(rounds)]
+    pts = synth.grid_points(w, h, 20, border=10)
+    n = len(pts)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (n_fr - 1, n, 2)), np.float32)
+    p = dr3.lk_params(win=(15, 15), max_level=3, max_iters=30, eps=0.01)
+    b = dr3.FrameBatch(ctx, w, h, win=(15, 15), max_level=3, capacity=n_fr)
+    ref = []
+    for r in range(rounds):
+        b.upload(0, sets[r]); b.build(0, n_fr, True)
+        ref.append(_track_all(dr3, ctx, b, n_fr, P, n, p))
+    assert not np.array_equal(ref[0][0], ref[1][0])
+    host = [ctx.host_alloc(s.shape) for s in sets]
+    for hbuf, s in zip(host, sets):
+        hbuf[...] = s
+    d_prev = ctx.to_device(P)
+    res = [(ctx.to_device(P), ctx.alloc((n_fr - 1) * n), ctx.alloc((n_fr - 1) * n * 4)) for _ in range(rounds)]
+    out = [(ctx.host_alloc((n_fr - 1, n, 2), np.float32), ctx.host_alloc(((n_fr - 1) * n,), np.uint8)) for _ in range(rounds)]
+    for r in range(rounds):                                         # no wait anywhere in this loop
+        b.upload_async(0, host[r]); b.build(0, n_fr, True)
+        b.track(n_fr - 1, 0, d_prev, res[r][0], n, res[r][1], res[r][2], p)
+        ctx.download_async(out[r][0], res[r][0]); ctx.download_async(out[r][1], res[r][1])
+    ctx.download_wait(); b.upload_wait()
+    for r in range(rounds):
+        assert np.array_equal(out[r][0].view(np.uint32), ref[r][0].view(np.uint32)) and np.array_equal(out[r][1], ref[r][1]), r
+    ctx.sync()
+    for hb in host:
+        ctx.host_free(hb)
+    for a, c in out:
+        ctx.host_free(a); ctx.host_free(c)
+    b.close()
