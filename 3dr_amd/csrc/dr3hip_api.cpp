@@ -43,7 +43,7 @@ struct dr3hip_ctx {
     // buffers -- a device bounce buffer (the frames as the host holds them; the compute stream changes the pitch out of it) and a
     // pinned host staging buffer (only used for pageable sources) per ring slot
     struct Xfer {
-        static constexpr int K = 4;
+        static constexpr int K = 24;       // x 8 MiB chunks: a whole batch of frames can be in flight ahead of the compute stream
         hipStream_t up = nullptr, down = nullptr;
         void* dev[K] = {nullptr}; void* pin[K] = {nullptr}; size_t cap = 0;
         hipEvent_t copied[K] = {nullptr}, consumed[K] = {nullptr}; bool used[K] = {false};

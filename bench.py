@@ -491,6 +491,12 @@ def main(argv=None):
     if args.workload == "kitti" and not args.no_frontend and have_gpu:
         two_streams = two_streams_leg(dist, ctx, dr3, frames, P, B, N_PTS, (W, H), params, step, (d_next, d_st), sync, max(4, min(args.steps, 20)))
 
+    # ---- the same step fed from the host every step (PCIe inclusive), pipelined ------------------------------------------------
+    stream = None
+    if args.workload == "kitti" and not args.no_host_api and have_gpu:
+        rx = d_next.download((B, N_PTS, 2), np.float32); rs = d_st.download((B, N_PTS), np.uint8)
+        stream = stream_leg(dist, ctx, dr3, frames, P, B, N_PTS, (W, H), params, sync, max(6, min(args.steps, 20)), rx, rs, have_gpu)
+
     # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------
     warp = None
     if not args.no_warp:
@@ -565,6 +571,7 @@ def main(argv=None):
                           "valu_issue": lk_valu_issue(lk_ms, B * N_PTS, lk_kernel_name) if args.workload == "kitti" else None},
             "hbm_copy_measured_GBps": copy_gbps,
             "host_api_pcie_inclusive": host_api,
+            "stream_h2d_inclusive": stream,
             "frontend": frontend,
             "lk_other_windows": lk_other,
             "lk_real_frames": lk_real,
@@ -810,6 +817,88 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
             d.free()
         b.close()
     return out
+
+
+def stream_leg(dist, ctx, dr3, frames, P, B, n_pts, size, params, sync, steps, resident_xy, resident_st, have_gpu):
+    """The headline step fed from the HOST, the way the reference receives every frame (src/handler.cpp:31-34,
+    tests/test_pipeline.cpp:71-73): every step uploads B + 1 NEW frames from pinned host memory (dr3hip_batch_upload_async: copy stream,
+    ring of device bounce buffers, pitch change + border on the compute stream), builds their pyramids and gradients, tracks B pairs and
+    downloads positions and status (dr3hip_download_async).  The upload of step s + 1 is in flight while step s computes; two frame
+    batches and two result sets alternate.  Three host frame sets rotate (set 0 = the resident run's frames: its results must come out
+    bit for bit).  Reported beside `value`, never as `value`.  The frame carried over between batches is uploaded again (1 / (B + 1))."""
+    if not have_gpu:
+        return None
+    import torch
+    W, H = size
+    n_sets = 3
+    L = len(frames)
+    host = [ctx.host_alloc((B + 1, H, W)) for _ in range(n_sets)]
+    for k, hb in enumerate(host):
+        for i in range(B + 1):
+            hb[i] = frames[(i + 2 * k) % L] if k else frames[i]
+    batches = [dr3.FrameBatch(ctx, W, H, win=(WIN, WIN), max_level=MAX_LEVEL, capacity=B + 1) for _ in range(2)]
+    d_prev = ctx.to_device(P)
+    res = [(ctx.to_device(P), ctx.alloc(B * n_pts), ctx.alloc(B * n_pts * 4)) for _ in range(2)]
+    out = [(ctx.host_alloc((B, n_pts, 2), np.float32), ctx.host_alloc((B, n_pts), np.uint8)) for _ in range(2)]
+    keep = {}
+
+    def run(n_steps, check_step=None):
+        batches[0].upload_async(0, host[0])
+        for s in range(n_steps):
+            b, r, o = batches[s % 2], res[s % 2], out[s % 2]
+            b.build(0, B + 1, True)
+            b.track(B, 0, d_prev, r[0], n_pts, r[1], r[2], params)
+            batches[(s + 1) % 2].upload_async(0, host[(s + 1) % n_sets])      # crosses the link while step s computes
+            ctx.download_wait()                                               # the results of step s - 1 are on the host
+            if check_step is not None and s - 1 == check_step:
+                keep["xy"], keep["st"] = out[(s - 1) % 2][0].copy(), out[(s - 1) % 2][1].copy()
+            ctx.download_async(o[0], r[0]); ctx.download_async(o[1], r[1])
+        ctx.download_wait()
+        sync()
+
+    run(4)
+    dist.barrier(); sync(); t0 = time.perf_counter()
+    run(steps, check_step=n_sets if steps > n_sets + 1 else None)             # step n_sets uses frame set 0 again
+    sync(); dist.barrier()
+    el = dist.max_over_ranks(time.perf_counter() - t0)
+    same = None
+    if "xy" in keep and resident_xy is not None:
+        same = bool(np.array_equal(keep["xy"].view(np.uint32), resident_xy.view(np.uint32)) and np.array_equal(keep["st"], resident_st))
+    # what the link delivers on this box: one pinned -> device copy of a frame set, HIP events on torch's stream
+    nbytes = host[0].nbytes
+    link = None
+    try:
+        th = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True); td = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % ctx.device)
+        td.copy_(th, non_blocking=True); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            td.copy_(th, non_blocking=True)
+        e1.record(); torch.cuda.synchronize()
+        link = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del th, td
+    except Exception:                                                         # noqa: BLE001 -- informational only
+        link = None
+    up_bytes = nbytes * (steps + 1)
+    down_bytes = (out[0][0].nbytes + out[0][1].nbytes) * steps
+    h2d = up_bytes / el / 1e9
+    kps = aggregate_rate(dist, B * n_pts * steps, el)
+    for b in batches:
+        b.upload_wait(); b.close()
+    for hb in host:
+        ctx.host_free(hb)
+    for a, c in out:
+        ctx.host_free(a); ctx.host_free(c)
+    for r in res:
+        for d in r:
+            d.free()
+    d_prev.free()
+    return {"keypoints_per_sec": kps, "ms_per_step": el / steps * 1e3, "steps": steps, "frames_uploaded_per_step": B + 1,
+            "h2d_GBps_achieved": h2d, "h2d_GBps_pinned_copy_measured": link, "h2d_frac_of_measured_link": None if not link else h2d / link,
+            "d2h_bytes_per_step": down_bytes // max(steps, 1), "bound": "host link (PCIe)" if link and h2d >= 0.7 * link else "compute / pipeline",
+            "results_identical_to_resident_run": same,
+            "note": "inputs cross PCIe every step: never `value`; a step is B + 1 frames up (pinned host memory), pyramid + gradient pass, "
+                    "tracker, positions + status down"}
 
 
 def lk_real_pair_leg(dist, ctx, dr3, sync, have_gpu):
