@@ -1001,6 +1001,10 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
         return fail(ctx, DR3HIP_ERANGE, "batch_create: window %dx%d exceeds this build's limit (%d)", win_w, win_h, DR3HIP_MAX_WIN);
     if (w <= win_w || h <= win_h)
         return fail(ctx, DR3HIP_ERANGE, "batch_create: image %dx%d must be larger than the window %dx%d", w, h, win_w, win_h);
+    // sides as at every entry point, and rows the tracker can address: it forms row offsets with 24-bit multiplies (__umul24), so the
+    // derivative pitch 4 (w + 2 pad) + 16 must stay below 2^24 -- a frame up to DR3HIP_BATCH_MAX_W pixels wide
+    if (!side_ok(w) || !side_ok(h) || w > DR3HIP_BATCH_MAX_W)
+        return fail(ctx, DR3HIP_ERANGE, "batch_create: frame %d x %d exceeds the batch limits (width <= %d)", w, h, DR3HIP_BATCH_MAX_W);
     DeviceGuard g(ctx->device);
     dr3hip_batch* b = new (std::nothrow) dr3hip_batch();
     if (!b) return fail(ctx, DR3HIP_ENOMEM, "batch_create: out of host memory");
@@ -1020,6 +1024,7 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
         v.pitch = align_up(lw + 2 * v.pad_x + 8, 64);
         v.dpitch = align_up(4 * (lw + 2 * v.pad_x) + 16, 128);
         const int rows = lh + 2 * v.pad_y;
+        if (v.dpitch >= (1 << 24)) { dr3hip_batch_destroy(b); return fail(ctx, DR3HIP_ERANGE, "batch_create: level %d rows of %d bytes exceed the tracker's 24-bit row pitch", l, v.dpitch); }
         // the kernels address a plane with 31-bit byte offsets
         if ((long long)v.dpitch * (rows + 17) > 0x7fffff00ll) {
             dr3hip_batch_destroy(b);

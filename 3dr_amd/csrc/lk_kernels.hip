@@ -193,8 +193,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
     const int nblk = PPW >= 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
     const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd)
-    // LDS rows per group: staging runs in rounds of SR rows; the run-time forms also read (and mask) the rows of the taps below the window
-    const int rhs = ((WIN ? rh : PPW >= 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
+    // LDS rows per group: staging runs in rounds of SR rows.  Every form but the compile-time column forms (WIN with PPW >= 4, whose
+    // tap_live() stops at the window) also reads (and masks) the rows of the taps below the window: a lane-item of NT rows starting at
+    // ity, up to 8 rows into the region, reaches row 8 + ity + NT <= win_h + 15 of the slice
+    const int rhs = (((WIN && PPW >= 4) ? rh : PPW >= 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
+    static_assert(!(WIN && PPW < 4) || 8 + 8 * ((WIN + 7) / 8 - 1) + 8 <= WIN + 15, "the slice of a group holds every row its lane-items read");
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps_lo = (float)(a.epsilon * (1.0 - 1e-6)), eps_hi = (float)(a.epsilon * (1.0 + 1e-6));
@@ -573,7 +576,7 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
     const int sr = 64 / ppw / (ppw >= 4 ? 8 : 16), lpd = ((a.win_w + 15) / 4) | 1;
     const bool fixed = a.win_w == a.win_h && (a.win_w == 15 || a.win_w == 21 || a.win_w == 30);
-    const int rhs = ((fixed ? a.win_h + 9 : ppw >= 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;
+    const int rhs = (((fixed && ppw >= 4) ? a.win_h + 9 : ppw >= 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;     // as in the kernel
     dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
     const size_t shmem = (size_t)ppw * rhs * lpd * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;

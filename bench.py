@@ -204,9 +204,9 @@ def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json"):
     WRITE_SIZE passes of this same script; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).
     PMC counters cannot be collected from inside the process being timed, so the figure is the recorded one
     for the same launch shape (default --batch); any other shape, or a summary recorded for other kernel sources, reports None."""
-    if batch != 256:
-        return None, None
     j, src = newest_profile(fname, kernel_source_hash(("pyr_kernels.hip", "warp_kernels.hip", "dr3hip_internal.h")))
+    if j and j.get("batch", 256) != batch:
+        return None, None
     if j:
         for name, t in j.get("kernels", {}).items():
             if kernel_substr in name and "hbm_bytes" in t:
@@ -528,7 +528,7 @@ def main(argv=None):
         lk_ms = ms_lk / max(n_lk, 1)
         ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
         ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
-        traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B)
+        traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B, "pmc_traffic.json" if args.workload == "kitti" else "pmc_traffic_hd.json")
         lk_kernel_name = lk_kernel_of(WIN, WIN)
         out = {
             "metric": "tracked_keypoints_per_sec",
@@ -557,6 +557,9 @@ def main(argv=None):
             "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)",
                          "bound": "hbm", "achieved": ach_l0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": traffic_l0,
+                         "frac_moved": None if not traffic_l0 else traffic_l0 / (l0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "frac_moved_note": "bytes the counters saw per launch / launch time / peak: SURVEY 8(d) counts the level-0 read twice "
+                                            "(once for pyrDown, once for Scharr); the fused kernel fetches it once",
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_l0, "avg_launch_ms": l0_ms, "launches": n_l0},
@@ -1043,9 +1046,11 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
             got = dsts[0].download(host.shape, host.dtype)
             ok = bool(np.array_equal(got.view(np.uint8), O.warp_perspective(host, jobs[0]["M"], (TW_, TH_)).view(np.uint8)))
         alg = NT_ * TW_ * TH_ * 2 * esz                  # esz read + esz written per dst pixel
-        traffic, tsrc = pmc_traffic("warp_perspective_kernel<%d," % typ, 256, "pmc_traffic_warp.json")
-        res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms, "verified_vs_oracle": ok,
-                     "roofline": {"kernel": "warp_perspective_kernel<%s>" % name.upper(), "bound": "hbm",
+        plan = dr3.warp_plan(jobs[0], typ)
+        kname = "warp_tile_8uc3_kernel" if plan["kernel"] == 2 else "warp_perspective_kernel<%d," % typ
+        traffic, tsrc = pmc_traffic(kname, 256, "pmc_traffic_warp.json")
+        res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms, "verified_vs_oracle": ok, "kernel_plan": plan,
+                     "roofline": {"kernel": ("warp_tile_8uc3_kernel (LDS-staged strips)" if plan["kernel"] == 2 else "warp_perspective_kernel<%s>" % name.upper()), "bound": "hbm",
                                   "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                                   "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg}}
@@ -1060,6 +1065,12 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
     return res
 
 
+def rotating_sets(set_bytes):
+    """how many distinct buffer sets a leg whose launch touches set_bytes must rotate over so that nothing it reads or writes is still in
+    the 256 MiB Infinity Cache from its previous use: at least 1 GiB of other sets' traffic lies between two uses of a set"""
+    return int(-(-(1 << 30) // max(int(set_bytes), 1))) + 1
+
+
 def remap_leg(dist, ctx, dr3, sync, tile, steps):
     """cv::remap as utils::warp_local calls it (reference src/utils.cpp:191) on one device-resident 4000x3000 8UC3 tile, twice:
     driven by the spherical maps read from two f32 planes (row a6: 3 + 8 B read, 3 B written per pixel) and with the maps generated
@@ -1068,35 +1079,53 @@ def remap_leg(dist, ctx, dr3, sync, tile, steps):
     h, w = tile.shape[:2]
     f = 0.9 * w
     lib = dr3.lib()
-    d_src, d_a, d_b = ctx.to_device(tile), ctx.alloc(h * w * 3), ctx.alloc(h * w * 3)
     out = {}
     if dist.rank == 0:
         from oracle import oracle as O
         u, v = O.spherical_map(w, h, f)
     else:
         u = v = np.zeros((h, w), np.float32)
-    d_u, d_v = ctx.to_device(u), ctx.to_device(v)
-    runs = (("maps_from_memory", 14, lambda: ctx._chk(lib.dr3hip_remap_bilinear_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_a.ptr, w, h, 3 * w,
-                                                                                         d_u.ptr, d_v.ptr, 4 * w))),
-            ("spherical_maps_in_kernel", 6, lambda: ctx._chk(lib.dr3hip_warp_local_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_b.ptr, 3 * w,
-                                                                                          dr3.WARP_SPHERICAL, C_float(f)))))
-    for name, bpp, run in runs:
+    # launches rotate over distinct buffer sets (rotating_sets): every launch streams from and to HBM, not the Infinity Cache
+    n_a, n_b = rotating_sets(h * w * (3 + 8 + 3)), rotating_sets(h * w * 6)
+    sets_a = [(ctx.to_device(tile), ctx.to_device(u), ctx.to_device(v), ctx.alloc(h * w * 3)) for _ in range(n_a)]
+    sets_b = [(sets_a[i][0] if i < n_a else ctx.to_device(tile), ctx.alloc(h * w * 3)) for i in range(n_b)]
+    it = {"a": 0, "b": 0}
+
+    def run_a():
+        d_src, d_u, d_v, d_a = sets_a[it["a"] % n_a]; it["a"] += 1
+        ctx._chk(lib.dr3hip_remap_bilinear_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_a.ptr, w, h, 3 * w, d_u.ptr, d_v.ptr, 4 * w))
+
+    def run_b():
+        d_src, d_b = sets_b[it["b"] % n_b]; it["b"] += 1
+        ctx._chk(lib.dr3hip_warp_local_dev(ctx.h, d_src.ptr, w, h, 3 * w, dr3.T_8UC3, d_b.ptr, 3 * w, dr3.WARP_SPHERICAL, C_float(f)))
+
+    for name, bpp, run, n_sets in (("maps_from_memory", 14, run_a, n_a), ("spherical_maps_in_kernel", 6, run_b, n_b)):
         ctx.profile_enable(True)
-        run(); sync(); ctx.profile_reset()
-        timed_region(dist, run, sync, steps, 0)
+        for _ in range(n_sets):
+            run()
+        sync(); ctx.profile_reset()
+        timed_region(dist, run, sync, max(steps, n_sets), 0)
         ms, n = ctx.profile_read(dr3.PROF_REMAP)
         ctx.profile_enable(False)
         k_ms = ms / max(n, 1)
         ach = bpp * w * h / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        out[name] = {"kernel_ms": k_ms, "roofline": {"kernel": "remap_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                                                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                                                     "algorithmic_bytes_per_launch": bpp * w * h}}
+        out[name] = {"kernel_ms": k_ms, "buffer_sets_rotated": n_sets,
+                     "roofline": {"kernel": "remap_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                                  "algorithmic_bytes_per_launch": bpp * w * h}}
     if dist.rank == 0:
-        a, b = d_a.download((h, w, 3), np.uint8), d_b.download((h, w, 3), np.uint8)
+        a, b = sets_a[0][3].download((h, w, 3), np.uint8), sets_b[0][1].download((h, w, 3), np.uint8)
         ref = O.remap(tile, u, v, n_threads=0)
         out["verified_vs_oracle"] = bool(np.array_equal(a, ref) and np.array_equal(b, ref))
     else:
         out["verified_vs_oracle"] = None
+    for t in sets_a:
+        for d in t:
+            d.free()
+    for i, t in enumerate(sets_b):
+        if i >= n_a:
+            t[0].free()
+        t[1].free()
     out["image"] = [w, h]
     return out
 
@@ -1108,26 +1137,33 @@ def halfsample_leg(dist, ctx, dr3, sync, tile, steps):
     grey = np.ascontiguousarray(tile[..., 1])
     big = np.tile(grey, (4, 4))
     h, w = big.shape
-    d_src, d_dst = ctx.to_device(big), ctx.alloc((h // 2) * (w // 2))
+    nbytes = w * h + (w // 2) * (h // 2)
+    n_sets = rotating_sets(nbytes)                              # 240 MB per launch would sit in the 256 MiB Infinity Cache: rotate
+    sets = [(ctx.to_device(big), ctx.alloc((h // 2) * (w // 2))) for _ in range(n_sets)]
     lib = dr3.lib()
+    it = [0]
 
     def run():
+        d_src, d_dst = sets[it[0] % n_sets]; it[0] += 1
         ctx._chk(lib.dr3hip_halfsample_dev(ctx.h, d_src.ptr, w, h, w, d_dst.ptr, w // 2, dr3.HALF_REF_X86))
 
     ctx.profile_enable(True)
-    run(); sync(); ctx.profile_reset()
-    timed_region(dist, run, sync, steps, 0)
+    for _ in range(n_sets):
+        run()
+    sync(); ctx.profile_reset()
+    timed_region(dist, run, sync, max(steps, n_sets), 0)
     ms, n = ctx.profile_read(dr3.PROF_HALF)
     ctx.profile_enable(False)
     k_ms = ms / max(n, 1)
     ok = None
     if dist.rank == 0:
         from oracle import oracle as O
-        got = d_dst.download((h // 2, w // 2), np.uint8)
+        got = sets[0][1].download((h // 2, w // 2), np.uint8)
         ok = bool(np.array_equal(got[:1500, :2000], O.halfsample(grey, O.HALF_REF_X86)) and np.array_equal(got[:1500, :2000], got[1500:3000, 2000:4000]))
-    nbytes = w * h + (w // 2) * (h // 2)
+    for a_, b_ in sets:
+        a_.free(); b_.free()
     ach = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    return {"image": [w, h], "kernel_ms": k_ms, "verified_vs_oracle": ok,
+    return {"image": [w, h], "kernel_ms": k_ms, "verified_vs_oracle": ok, "buffer_sets_rotated": n_sets,
             "roofline": {"kernel": "halfsample_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": nbytes}}
 
@@ -1164,7 +1200,9 @@ def kitti_warp_leg(dist, ctx, dr3, synth, sync, tile, steps):
     alg = NJ * W_ * H_ * 6
     return {"frames_per_launch": NJ, "kernel_ms": k_ms, "verified_vs_oracle": ok, "mpix_per_s": aggregate_rate(dist, NJ * W_ * H_ * steps / 1e6, el),
             "kernel_only_mpix_per_s": NJ * W_ * H_ / 1e6 / (k_ms * 1e-3),
-            "roofline": {"kernel": "warp_perspective_kernel<8UC3>", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9,
+            "kernel_plan": dr3.warp_plan(jobs[3], dr3.T_8UC3),
+            "roofline": {"kernel": "warp_tile_8uc3_kernel (LDS-staged strips)" if dr3.warp_plan(jobs[3], dr3.T_8UC3)["kernel"] == 2 else "warp_perspective_kernel<8UC3>",
+                         "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg}}
 
@@ -1177,17 +1215,25 @@ def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
     H = np.array([[np.cos(a), -np.sin(a), -0.45 * TW_], [np.sin(a), np.cos(a), 35.0], [1e-5, -6e-6, 1.0]], np.float32)
     Hinv, T, M, (nw, nh) = dr3.stitch_geometry(H, TW_, TH_)
     op = (3 * nw + 255) // 256 * 256
-    d_l, d_r, d_o = ctx.to_device(tile), ctx.to_device(np.roll(tile, -int(0.45 * TW_), axis=1)), ctx.alloc(op * nh)
+    right = np.roll(tile, -int(0.45 * TW_), axis=1)
+    n_sets = rotating_sets(2 * TW_ * TH_ * 3 + op * nh)         # 130 MB per launch would sit in the 256 MiB Infinity Cache: rotate
+    sets = [(ctx.to_device(tile), ctx.to_device(right), ctx.alloc(op * nh)) for _ in range(n_sets)]
+    d_l, d_r, d_o = sets[0]
     Tc, Mc = np.ascontiguousarray(T.reshape(9)), np.ascontiguousarray(M.reshape(9))
     L = dr3.lib()
+    it = [0]
 
     def step():
-        ctx._chk(L.dr3hip_stitch_compose_dev(ctx.h, d_l.ptr, TW_, TH_, 3 * TW_, d_r.ptr, TW_, TH_, 3 * TW_, Tc.ctypes.data, Mc.ctypes.data,
-                                             nw, nh, 0.5, 0.5, 0.0, d_o.ptr, op))
+        a_l, a_r, a_o = sets[it[0] % n_sets]; it[0] += 1
+        ctx._chk(L.dr3hip_stitch_compose_dev(ctx.h, a_l.ptr, TW_, TH_, 3 * TW_, a_r.ptr, TW_, TH_, 3 * TW_, Tc.ctypes.data, Mc.ctypes.data,
+                                             nw, nh, 0.5, 0.5, 0.0, a_o.ptr, op))
 
     ctx.profile_enable(True)
-    step(); sync()
+    for _ in range(n_sets):
+        step()
+    sync()
     ctx.profile_reset()
+    steps = max(steps, n_sets)
     el = timed_region(dist, step, sync, steps, 0)
     ms, n = ctx.profile_read(dr3.PROF_STITCH)
     ctx.profile_enable(False)
@@ -1195,12 +1241,13 @@ def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
     if dist.rank == 0:                                     # the timed pair against the oracle's two warps + addWeighted
         from oracle import oracle as O
         got = d_o.download((nh, op), np.uint8)[:, :3 * nw].reshape(nh, nw, 3)
-        ok = bool(np.array_equal(got, O.stitch_compose(tile, np.roll(tile, -int(0.45 * TW_), axis=1), H)))
-    for d in (d_l, d_r, d_o):
-        d.free()
+        ok = bool(np.array_equal(got, O.stitch_compose(tile, right, H)))
+    for t in sets:
+        for d in t:
+            d.free()
     k_ms = ms / max(n, 1)
     alg = 2 * TW_ * TH_ * 3 + nw * nh * 3                 # both sources read once + the canvas written once
-    return {"canvas": [nw, nh], "kernel_ms": k_ms, "verified_vs_oracle": ok, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
+    return {"canvas": [nw, nh], "kernel_ms": k_ms, "verified_vs_oracle": ok, "buffer_sets_rotated": n_sets, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
             "roofline": {"kernel": "stitch_compose_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
             "replaces": "reference passes: warp right (3 r + 3 w per canvas px), warp left (3 r + 3 w), addWeighted (6 r + 3 w)"}

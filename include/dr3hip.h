@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define DR3HIP_VERSION 101
+#define DR3HIP_BATCH_MAX_W 4000000   /* widest frame of a dr3hip_batch: the tracker addresses rows of 4 (w + 2 pad) + 16 bytes with 24-bit pitches */
 
 /* error codes */
 #define DR3HIP_OK        0

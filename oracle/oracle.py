@@ -33,10 +33,19 @@ class LKParams(C.Structure):
                 ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
 
 
+def _under_profiler():
+    """rocprofv3 preloads a library that initialises the GPU in every process of the tree: build tools (make, sh, gcc ...) must not be
+    started from such a process (this pool forbids an exec from a GPU-initialised process)"""
+    return any(k.startswith(("ROCPROFILER", "ROCPROF_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
 def build(force=False):
     """Compile the oracle with the committed Makefile (gcc only)."""
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "dr3_oracle.c")):
+        if _under_profiler():
+            raise RuntimeError("the oracle library is missing or older than its source and this process runs under a profiler: build it "
+                               "first, outside the profiler (python -c 'import __graft_entry__ as g; g.build()')")
         subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -56,6 +65,8 @@ def build_native():
     path = os.path.join(_HERE, name)
     try:
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "dr3_oracle.c")):
+            if _under_profiler():
+                return None
             subprocess.check_call(["make", "-C", _HERE, "NATIVE=" + name, name], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return path
     except (subprocess.CalledProcessError, OSError):

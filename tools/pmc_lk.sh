@@ -2,6 +2,8 @@
 # (counters only: no other trace domain; the program itself after "--"), then per-kernel medians.
 set -e
 R=$GRAFT_REPO_ROOT
+# libraries (product and oracle) are built before the first profiler line: build tools must not start under the profiler
+( cd $R && python3 -c "import __graft_entry__ as g; g.build()" > /dev/null )
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-host-api $@"
 run() { n=$1; shift
