@@ -92,6 +92,15 @@ class Dist:
         self.dist.broadcast(t, src=0)
         return bytes(t.cpu().tolist())
 
+    def all_gather_bytes(self, payload):
+        """every rank's `payload` (equal lengths) as a list indexed by rank"""
+        if not self.pg:
+            return [bytes(payload)]
+        t = self.torch.tensor(list(payload), dtype=self.torch.uint8, device=self.device)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [bytes(o.cpu().tolist()) for o in out]
+
     def max_over_ranks(self, x):
         if not self.pg:
             return float(x)
@@ -313,6 +322,8 @@ def main(argv=None):
                     help="kitti = BASELINE configs[1] (the metric's configuration, default); hd = the per-GPU share of configs[4]: "
                          "1920x1080 pairs, 5000 corners, 5-level pyramid, 21x21 window (default batch 64)")
     ap.add_argument("--no-warp", action="store_true", help="skip the configs[2] warp leg")
+    ap.add_argument("--sharded-paste", default=None, metavar="WxH", help="N > 1: run the canvas-sharded paste leg (one panorama per step across "
+                    "the job) on tiles of this size even with --no-warp (default with the warp leg: 4000x3000)")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detect -> track front-end leg")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-buffer leg (its single-pair launches "
                     "share kernel symbols with the timed region and would skew a profiler's per-kernel averages)")
@@ -502,6 +513,13 @@ def main(argv=None):
     if not args.no_warp:
         warp = warp_leg(dist, ctx, dr3, synth, sync, steps=max(3, min(args.steps, 10)))
 
+    # ---- SURVEY 8(e), warp side: the canvas of ONE panorama sharded over the ranks by rows (N > 1) -----------------------------
+    paste_sharded = None
+    if dist.world > 1 and (args.sharded_paste or not args.no_warp):
+        tw_, th_ = (int(v) for v in (args.sharded_paste or "4000x3000").lower().split("x"))
+        paste_sharded = paste_sharded_leg(dist, ctx, dr3, synth, sync, cheap_tile(synth, tw_, th_), max(3, min(args.steps, 10)),
+                                          feather=max(8, min(300, tw_ // 12)))
+
     # ---- RCCL broadcast of a reference frame's pyramid through the library's own communicator.
     # Untimed, after every measurement, N > 1 over real GPUs only (RCCL refuses ranks that share a device), and under
     # a watchdog: a communicator that cannot come up must cost the run this one sub-object, not its JSON line.
@@ -582,6 +600,7 @@ def main(argv=None):
             "two_streams": two_streams,
             "sparse_align": align,
             "warp": warp,
+            "paste_canvas_sharded": paste_sharded,
             "ref_pyramid_bcast": ref_bcast,
             "cpu_baseline": cpu,
         }
@@ -1253,11 +1272,8 @@ def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
             "replaces": "reference passes: warp right (3 r + 3 w per canvas px), warp left (3 r + 3 w), addWeighted (6 r + 3 w)"}
 
 
-def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
-    """configs[2] as the reference really runs it (Panorama::paste_images, src/panorama.cpp:143-154): the 8 tiles
-    are pasted into ONE 32FC4 weighted canvas (4 x 2 layout, ~10 % overlap, feathering width 300) by the fused
-    warp + feather + accumulate kernel, then normalised to 8UC3.  One step = 8 pastes + 1 normalise."""
-    TH_, TW_ = tile.shape[:2]
+def paste_geometry(dr3, synth, TW_, TH_):
+    """the 8 forward homographies (already multiplied by top_left, src/panorama.cpp:148) of the 4 x 2 tile layout and the canvas size"""
     Ms = []
     for i in range(8):
         M = synth.tile_homography(i, TW_, TH_).astype(np.float64)
@@ -1266,6 +1282,60 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
     boxes = [dr3.panorama_bbox(M, TW_, TH_) for M in Ms]
     cw = (max(b[2] for b in boxes) + 64) // 64 * 64
     ch = max(b[3] for b in boxes) + 16
+    return Ms, boxes, cw, ch
+
+
+def paste_sharded_leg(dist, ctx, dr3, synth, sync, tile, steps, feather=300):
+    """SURVEY 8(e), the warp side, as DESIGN section 6 states it: ONE panorama per step across the whole job (reference
+    Panorama::paste_images, src/panorama.cpp:144-154).  The canvas rows are cut into `world` slabs; every rank pastes all 8 tiles
+    into ITS slab (dr3hip_panorama_add_slab: the geometry stays that of the whole canvas) and normalises it -- no exchange between
+    ranks, no reduction.  Time = MAX over ranks of the barrier-bracketed region; the rate is the JOB's (tile pixels of one panorama
+    per step): strong scaling.  Check: every rank hashes its slab of the finished 8UC3 panorama, rank 0 pastes the whole canvas alone
+    and compares its rows with the gathered hashes."""
+    import hashlib
+    TH_, TW_ = tile.shape[:2]
+    Ms, boxes, cw, ch = paste_geometry(dr3, synth, TW_, TH_)
+    y0, y1 = ch * dist.rank // dist.world, ch * (dist.rank + 1) // dist.world
+    rows = y1 - y0
+    d_img = ctx.to_device(tile)
+    d_slab, d_out = ctx.alloc(cw * rows * 16), ctx.alloc(cw * rows * 3)
+
+    def step():
+        d_slab.zero()
+        for M in Ms:
+            ctx.panorama_add_slab(d_img, TW_, TH_, TW_ * 3, d_slab, cw, ch, cw * 16, M, feather, y0, y1)
+        ctx.panorama_normalize(d_slab, cw, rows, cw * 16, d_out, cw * 3)
+
+    step(); sync()
+    el = timed_region(dist, step, sync, steps, 0)
+    mine = hashlib.sha256(np.ascontiguousarray(d_out.download((rows, cw, 3), np.uint8)).tobytes()).digest()
+    gathered = dist.all_gather_bytes(mine)
+    ok = None
+    if dist.rank == 0:
+        d_c, d_o = ctx.alloc(cw * ch * 16), ctx.alloc(cw * ch * 3)
+        d_c.zero()
+        for M in Ms:
+            ctx.panorama_add_slab(d_img, TW_, TH_, TW_ * 3, d_c, cw, ch, cw * 16, M, feather, 0, ch)
+        ctx.panorama_normalize(d_c, cw, ch, cw * 16, d_o, cw * 3)
+        sync()
+        whole = d_o.download((ch, cw, 3), np.uint8)
+        ok = all(hashlib.sha256(np.ascontiguousarray(whole[ch * r // dist.world:ch * (r + 1) // dist.world]).tobytes()).digest() == gathered[r]
+                 for r in range(dist.world))
+        d_c.free(); d_o.free()
+    for d in (d_img, d_slab, d_out):
+        d.free()
+    return {"canvas": [cw, ch], "tiles": 8, "slabs": dist.world, "rows_per_slab": [ch * (r + 1) // dist.world - ch * r // dist.world for r in range(dist.world)],
+            "scaling": "strong (one panorama per step across the job; canvas row slabs, no reduction)",
+            "ms_per_panorama": el / steps * 1e3, "tile_mpix_per_s_job": 8 * TW_ * TH_ * steps / 1e6 / el,
+            "slabs_equal_the_single_gpu_canvas": ok}
+
+
+def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
+    """configs[2] as the reference really runs it (Panorama::paste_images, src/panorama.cpp:143-154): the 8 tiles
+    are pasted into ONE 32FC4 weighted canvas (4 x 2 layout, ~10 % overlap, feathering width 300) by the fused
+    warp + feather + accumulate kernel, then normalised to 8UC3.  One step = 8 pastes + 1 normalise."""
+    TH_, TW_ = tile.shape[:2]
+    Ms, boxes, cw, ch = paste_geometry(dr3, synth, TW_, TH_)
     d_img = ctx.to_device(tile)
     d_canvas = ctx.alloc(cw * ch * 16)
     d_out = ctx.alloc(cw * ch * 3)

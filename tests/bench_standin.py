@@ -2,7 +2,10 @@
 bench.py's launch path (`--gpus N` -> N child ranks -> barrier-bracketed timing -> rank 0's JSON line) on a box without
 GPUs.  Nothing here computes anything: a "step" is a sleep whose length depends on the rank, so that the test can tell
 MAX-over-ranks time from any single rank's.  bench.py labels a line produced this way "data": "standin ..."; the product
-path never imports this module (tests/test_abi.py checks that nothing under 3dr_amd/ or include/ refers to tests/)."""
+path never imports this module (tests/test_abi.py checks that nothing under 3dr_amd/ or include/ refers to tests/).
+The one exception to "computes nothing" is the panorama paste: the canvas-sharded leg (bench.paste_sharded_leg) checks that the row
+slabs of all ranks equal the canvas one rank pastes alone, so the stand-in pastes for real -- through the CPU checker (oracle/), on
+the tiny tiles the test asks for -- cutting the rows [y0, y1) out of the whole-canvas result as dr3hip_panorama_add_slab defines."""
 import os
 import time
 
@@ -28,14 +31,24 @@ def lk_params(**kw):
 
 
 class _Buf:
-    def __init__(self, nbytes):
-        self.nbytes, self.ptr = int(nbytes), 1
+    def __init__(self, nbytes, arr=None):
+        self.nbytes, self.ptr, self.arr = int(nbytes), 1, arr
 
     def download(self, shape, dtype, offset=0):
+        if self.arr is not None:
+            return np.frombuffer(np.ascontiguousarray(self.arr).tobytes(), dtype)[:int(np.prod(shape))].reshape(shape).copy()
         return np.ones(shape, dtype)
+
+    def zero(self):
+        self.arr = None
 
     def free(self):
         pass
+
+
+def panorama_bbox(M, w, h):
+    from oracle import oracle as O
+    return O.panorama_bbox(M, w, h)
 
 
 class Context:
@@ -47,7 +60,19 @@ class Context:
     def sync(self): pass
     def close(self): pass
     def alloc(self, nbytes): return _Buf(nbytes)
-    def to_device(self, arr): return _Buf(np.asarray(arr).nbytes)
+    def to_device(self, arr): return _Buf(np.asarray(arr).nbytes, np.asarray(arr))
+
+    def panorama_add_slab(self, d_img, w, h, istride, d_slab, cw, ch, cstride, M, feathering_width, y0, y1):
+        from oracle import oracle as O
+        full = np.zeros((ch, cw, 4), np.float32)
+        if d_slab.arr is not None:
+            full[y0:y1] = d_slab.arr
+        O.panorama_add(d_img.arr, full, M, feathering_width)          # the whole-canvas geometry; the slab keeps its own rows
+        d_slab.arr = full[y0:y1].copy()
+
+    def panorama_normalize(self, d_canvas, cw, ch, cstride, d_out, ostride):
+        from oracle import oracle as O
+        d_out.arr = O.normalize_canvas(d_canvas.arr if d_canvas.arr is not None else np.zeros((ch, cw, 4), np.float32))
     def profile_enable(self, on=True): pass
     def profile_reset(self): self.prof = {}
 

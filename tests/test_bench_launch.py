@@ -59,3 +59,19 @@ def test_more_ranks_than_gpus_is_refused_not_shared():
     del env["DR3_BENCH_BACKEND"]
     r, lines = _run(["--gpus", "2"] + COMMON, env)
     assert r.returncode == 4 and not lines and "dr3hip_device_count() = 0" in r.stderr
+
+
+def test_canvas_sharded_paste_runs_on_two_ranks_and_equals_the_single_rank_canvas():
+    """SURVEY 8(e), warp side: two gloo ranks paste ONE panorama -- each all 8 tiles into its own slab of canvas rows -- and rank 0
+    checks the gathered slab hashes against the canvas it pastes alone (the stand-in pastes through the CPU checker)"""
+    r, lines = _run(["--gpus", "2", "--sharded-paste", "96x64"] + COMMON, _env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[0])
+    p = d["paste_canvas_sharded"]
+    assert p["slabs"] == 2 and sum(p["rows_per_slab"]) == p["canvas"][1] and p["slabs_equal_the_single_gpu_canvas"] is True
+    assert p["scaling"].startswith("strong") and p["tile_mpix_per_s_job"] > 0
+
+
+def test_single_rank_has_no_sharded_paste_leg():
+    r, lines = _run(["--gpus", "1", "--sharded-paste", "96x64"] + COMMON, _env())
+    assert r.returncode == 0 and json.loads(lines[0])["paste_canvas_sharded"] is None
