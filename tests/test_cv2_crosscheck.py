@@ -50,3 +50,24 @@ def test_warp_perspective_matches_opencv(O, kitti, synth):
     f4 = np.dstack([f, np.ones(f.shape[:2], np.float32)])
     got = O.warp_perspective(f4, M, (1400, 480)); ref = cv2.warpPerspective(f4, M, (1400, 480), flags=cv2.INTER_LINEAR)
     assert np.abs(got - ref).max() <= np.spacing(np.float32(255.0))          # 1 ULP (north_star)
+
+
+def test_remap_matches_opencv(O, kitti):
+    """cv::remap as utils::warp_local calls it (reference src/utils.cpp:189-194): f32 maps, INTER_LINEAR, BORDER_CONSTANT 0 -- the
+    spherical maps of utils::compute_spherical_warping and a map with values outside the image, on ties of the 1/32-px grid and
+    beyond the int16 range of the fixed-point coordinates"""
+    A, B = kitti
+    bgr = np.stack([A, B, A], -1)
+    h, w = A.shape
+    u, v = O.spherical_map(w, h, 0.9 * w)
+    want = cv2.remap(bgr, u, v, cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT, borderValue=0)
+    assert np.array_equal(O.remap(bgr, u, v), want)
+    rng = np.random.default_rng(11)
+    u2 = (rng.uniform(-40, w + 40, (h, w)).astype(np.float32) * 64).round() / 64          # every value on a 1/64-px tie or grid point
+    v2 = (rng.uniform(-40, h + 40, (h, w)).astype(np.float32) * 64).round() / 64
+    u2[::7, ::5] = 40000.5; v2[::9, ::11] = -40000.25
+    want = cv2.remap(bgr, u2, v2, cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT, borderValue=0)
+    assert np.array_equal(O.remap(bgr, u2, v2), want)
+    f = bgr.astype(np.float32)
+    got = O.remap(f, u, v); ref = cv2.remap(f, u, v, cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT, borderValue=0)
+    assert np.abs(got - ref).max() <= np.spacing(np.float32(255.0))
