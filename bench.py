@@ -443,6 +443,18 @@ def main(argv=None):
         r_res = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_RASTER, want_iters=True)
         raster = O.order_agreement((g_xy, g_st, None, o_L, o_it), r_res, po, 1e-3)
 
+    # ---- how many Gauss-Newton iteration-levels a point takes, and the slowest point of a lock-step group (what a wave executes):
+    # one more launch, untimed, that also writes the iteration counts
+    lk_iters = None
+    if have_gpu:
+        d_it = ctx.alloc(B * N_PTS * levels * 4)
+        batch.track(B, 0, d_prev, d_next, N_PTS, d_st, d_err, params, d_iters=d_it); sync()
+        it = d_it.download((B, N_PTS, levels), np.int32).sum(2)
+        ppw = int(lk_kernel_of(WIN, WIN).split(",")[1])
+        lk_iters = {"mean_iteration_levels_per_point": float(it.mean()), "points_per_wave": ppw,
+                    "mean_iteration_levels_of_slowest_in_group": float(it[:, :N_PTS // ppw * ppw].reshape(B, -1, ppw).max(2).mean())}
+        d_it.free()
+
     # ---- what this box's HBM delivers on a plain device-to-device copy (report beside the nominal 8 TB/s)
     copy_gbps = None
     if dist.rank == 0 and have_gpu:
@@ -588,6 +600,7 @@ def main(argv=None):
             "lk_kernel": {"kernel": lk_kernel_name, "avg_launch_ms": lk_ms,
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),
                           "unique_bytes_per_launch": lk_unique_bytes_per_pair(N_PTS, levels, WIN) * B,
+                          "iterations": lk_iters,
                           "note": "VALU-issue bound, not HBM-bound (SURVEY 8d): no HBM fraction claimed",
                           "valu_issue": lk_valu_issue(lk_ms, B * N_PTS, lk_kernel_name) if args.workload == "kitti" else None},
             "hbm_copy_measured_GBps": copy_gbps,

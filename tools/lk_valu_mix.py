@@ -10,7 +10,7 @@ nest (level loop x iteration loop; deeper loops are the rare re-staging paths) a
 class and the average issue cost.  bench.py combines the average with the PMC instruction count of the same kernel
 (profiles/*/pmc_lk.json) into lk_kernel.valu_issue.
 
-usage: tools/lk_valu_mix.py [kernel-substring] [levels] [iteration-levels per wave] > profiles/<round>/valu_mix.json
+usage: tools/lk_valu_mix.py [kernel-substring] [levels] [iteration-levels per wave] [measured VALU per wave] > profiles/<round>/valu_mix.json
 """
 import hashlib
 import json
@@ -65,17 +65,24 @@ def cost_of(line):
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "lk_trackg_kernelILi15ELi4ELi1E"
+    want = sys.argv[1] if len(sys.argv) > 1 else "lk_trackg_kernelILi15ELi8ELi2E"
     levels = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     iter_levels = float(sys.argv[3]) if len(sys.argv) > 3 else 11.3
+    measured = float(sys.argv[4]) if len(sys.argv) > 4 else None          # SQ_INSTS_VALU / SQ_WAVES of the same launch shape (pmc_lk.json)
     isa = compile_isa()
     m = re.search(r"^(_Z\S*%s\S*):[^\n]*\n(.*?)s_endpgm" % re.escape(want), isa, re.S | re.M)
     if not m:
         sys.exit("kernel %s not found" % want)
     body = m.group(2).split("\n")
-    # loop depth of every block from the compiler's annotations
+    # loop depth of every block from the compiler's annotations.  Blocks of the level loop (depth 1) BEHIND the last block of the
+    # iteration loop (depth 2) are the level-0 residual and the per-level bookkeeping after the iterations: the residual runs once
+    # per wave, not once per level (it is the bulk of that tail), so the whole tail is weighted 1.
     depth, header = 0, {}
     w_of_depth = {0: 1.0, 1: levels, 2: iter_levels}
+    last_d2 = max((i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l) and
+                   re.search(r"Depth=2", " ".join(x for x in body[i:i + 8] if x.startswith(".LBB") or x.strip().startswith(";")))), default=-1)
+    # the end of that last depth-2 block: the next label
+    tail_from = next((i for i in range(last_d2 + 1, len(body)) if re.match(r"^\.LBB\d+_\d+:", body[i])), len(body)) if last_d2 >= 0 else len(body)
     tot = {"fast": 0.0, "std": 0.0, "trans": 0.0}
     static = {"fast": 0, "std": 0, "trans": 0}
     cur_depth = 0
@@ -97,12 +104,13 @@ def main():
             continue
         clk, cls = c
         static[cls] += 1
-        tot[cls] += w_of_depth.get(cur_depth, 0.0)
+        tot[cls] += 1.0 if (cur_depth == 1 and i >= tail_from) else w_of_depth.get(cur_depth, 0.0)
     n = sum(tot.values())
     cycles = 2 * tot["fast"] + 4 * tot["std"] + 8 * tot["trans"]
     dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
     out = {"kernel": m.group(1), "kernel_demangled": dem, "source_hash": source_hash(),
-           "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0},
+           "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0, "level_loop_tail_behind_the_iterations": 1.0},
+           "measured_valu_per_wave": measured, "predicted_over_measured": None if not measured else round(n / measured, 4),
            "static_valu": static, "weighted_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
            "weighted_valu_per_wave_total": round(n, 1), "issue_clocks_per_wave": round(cycles, 1),
            "avg_issue_clocks_per_valu": round(cycles / n, 4),
