@@ -305,7 +305,7 @@ def cheap_tile(synth, w, h):
     """4000x3000x3 u8 tile: low-res analytic texture upsampled + deterministic fine pattern
     (content does not influence warp timing; the full analytic generator would take minutes)"""
     f = 8
-    low = synth.Texture(w // f, h // f, channels=3).render()
+    low = synth.Texture(-(-w // f), -(-h // f), channels=3).render()
     big = np.repeat(np.repeat(low, f, axis=0), f, axis=1)[:h, :w].astype(np.int16)
     yy, xx = np.mgrid[0:h, 0:w]
     big += (((xx * 7 + yy * 13) & 15) - 8)[..., None].astype(np.int16)
