@@ -24,6 +24,7 @@ for _ in range(10):
 ctx.sync()
 ms, n = ctx.profile_read(dr3.PROF_WARP)
 k = bench.kitti_warp_leg(dist, ctx, dr3, synth, ctx.sync, tile, 10) if os.environ.get("WQ_KITTI", "1") == "1" else {"kernel_ms": 0.0, "roofline": {"frac": 0.0}, "verified_vs_oracle": None}
+print("plan", dr3.warp_plan(jobs[0], dr3.T_8UC3), end=" ")
 print("8uc3 %.4f ms frac %.3f | kitti %.4f ms frac %.3f ok %s | %s" % (ms / n, 576e6 / (ms / n * 1e-3) / 8e12, k["kernel_ms"], k["roofline"]["frac"], k["verified_vs_oracle"],
       os.path.basename(os.environ.get("DR3HIP_LIB", ""))))
 ctx.close()
