@@ -242,7 +242,10 @@ def lk_valu_issue(lk_ms, waves, kernel):
     n_wave_instr = k["valu_per_wave"] * (waves / k["points_per_wave"])
     ach = n_wave_instr / (lk_ms * 1e-3) / 1e9
     peak = 1024 * 2.4 / clk
+    ghz = k.get("clock_ghz")
     return {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "frac_at_profiled_clock": None if not ghz else ach / (1024 * ghz / clk),
+            "valu_mix_predicted_over_measured": mix.get("predicted_over_measured"),
             "avg_issue_clocks_per_valu": clk, "valu_per_wave": k["valu_per_wave"], "salu_per_wave": k.get("salu_per_wave"),
             "points_per_wave": k["points_per_wave"],
             "valu_pipe_busy_profiled": k.get("valu_issue_busy"), "scalar_pipe_busy_profiled": k.get("salu_issue_busy"),

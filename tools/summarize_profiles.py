@@ -109,7 +109,31 @@ def main(src, dst):
     json.dump(summary, open(os.path.join(dst, "pmc_fetch_write_summary.json"), "w"), indent=1)
     json.dump({"note": "bytes per launch, median over dispatches; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; "
                        "bench.py --steps 2 --warmup 1 --no-cpu --no-warp (256 frames / 256 pairs x 2000 points per launch)",
-               "source_hash": source_hash(TRAFFIC_HASH_FILES), "kernels": traffic}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+               "batch": 256, "source_hash": source_hash(TRAFFIC_HASH_FILES), "kernels": traffic}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    # configs[4]'s per-GPU share (bench.py --workload hd: 64 pairs of 1920 x 1080 per launch)
+    for name, dstname in (("prof_hd", "kernel_stats_hd.csv"), ("prof_all", "kernel_stats_all_legs.csv")):
+        ks2 = os.path.join(src, name, "bench_kernel_stats.csv")
+        if os.path.exists(ks2):
+            shutil.copy(ks2, os.path.join(dst, dstname))
+    hd = {}
+    for counter, sub, stem in (("FETCH_SIZE", "pmc_hd_fetch", "fetch"), ("WRITE_SIZE", "pmc_hd_write", "write")):
+        p = os.path.join(src, sub, stem + "_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        for k, v in per_kernel(p, counter, largest_grid_only=True).items():
+            t = hd.setdefault(k, {})
+            kb = statistics.median(v)
+            if counter == "FETCH_SIZE":
+                t["fetch_bytes_raw"] = kb * 1024.0; t["fetch_bytes"] = kb * 1024.0 * 2.0
+            else:
+                t["write_bytes"] = kb * 1024.0
+    for k, t in hd.items():
+        if "fetch_bytes" in t and "write_bytes" in t:
+            t["hbm_bytes"] = t["fetch_bytes"] + t["write_bytes"]
+    if hd:
+        json.dump({"note": "bytes per launch of bench.py --workload hd (64 pairs of 1920 x 1080, 5000 points, 5 levels, 21 x 21), the largest "
+                           "dispatch of each kernel; FETCH_SIZE doubled (gfx950)", "batch": 64, "source_hash": source_hash(TRAFFIC_HASH_FILES),
+                   "kernels": hd}, open(os.path.join(dst, "pmc_traffic_hd.json"), "w"), indent=1)
     # warp / paste legs (tools/profile_warp.sh): same treatment, separate files
     ks = os.path.join(src, "prof_warp", "warp_kernel_stats.csv")
     if os.path.exists(ks):
@@ -141,7 +165,10 @@ def main(src, dst):
         for row in csv.DictReader(open(f, newline="")):
             if "lk_track" not in row["Kernel_Name"]:
                 continue
-            acc.setdefault((row["Kernel_Name"], row["Grid_Size"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            c = acc.setdefault((row["Kernel_Name"], row["Grid_Size"]), {})
+            c.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):       # the dispatch's own duration, for its clock
+                c.setdefault("_clock_ghz", []).append(float(row["Counter_Value"]) / 8.0 / max(1.0, float(row["End_Timestamp"]) - float(row["Start_Timestamp"])))
     kernels = {}
     for (name, grid), c in acc.items():
         m = {k: statistics.median(v) for k, v in c.items()}
@@ -159,7 +186,8 @@ def main(src, dst):
              "wait_inst_any_frac": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
              "wait_any_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
              "lds_per_wave": m.get("SQ_INSTS_LDS", 0) / w, "vmem_rd_per_wave": m.get("SQ_INSTS_VMEM_RD", 0) / w,
-             "branch_per_wave": m.get("SQ_INSTS_BRANCH", 0) / w, "smem_per_wave": m.get("SQ_INSTS_SMEM", 0) / w}
+             "branch_per_wave": m.get("SQ_INSTS_BRANCH", 0) / w, "smem_per_wave": m.get("SQ_INSTS_SMEM", 0) / w,
+             "clock_ghz": m.get("_clock_ghz")}
         # keep the bench's own launch shape when a kernel ran at several: the shape with the most dispatches (the timed region and
         # its pre-roll), the larger one on a tie
         e["dispatches"] = len(c.get("SQ_WAVES", []))
@@ -174,14 +202,13 @@ def main(src, dst):
                     e["avg_issue_clocks_per_valu"] = clk
                     e["valu_issue_busy"] = e["valu_per_wave"] * e["waves"] * clk / (1024.0 * e["elapsed_clocks"])
                     e["salu_issue_busy"] = e["salu_per_cu_clock"]           # one scalar issue per CU clock
-                    e["clock_ghz"] = None
         json.dump({"note": "tracker kernels at the bench's launch shapes, rocprofv3 --pmc (tools/pmc_lk.sh), medians over dispatches; "
                            "active_inst_valu_per_cu_clock calibrates to 0.97 for a saturated 4-clock stream and 1.94 for a saturated "
-                           "2-clock stream (tools/pmc_ubench.sh, profiles/r02_lk/pmc_ubench_calibration.txt); valu_issue_busy = "
+                           "2-clock stream (tools/pmc_ubench.sh, profiles/r02_v1/pmc_ubench.txt); valu_issue_busy = "
                            "VALU instructions x average issue clocks of the kernel's mix (valu_mix.json) / (1024 SIMDs x elapsed clocks)",
                    "source_hash": source_hash(LK_HASH_FILES), "kernels": kernels}, open(os.path.join(dst, "pmc_lk.json"), "w"), indent=1)
     for name in ("bench_default_run.json", "bench_hd_run.json", "pmc_lk_summary.txt", "pmc_warpq_summary.txt", "ubench_valu_rate.json",
-                 "pmc_ubench.txt"):
+                 "pmc_ubench.txt", "bench_gpus2_gloo_rehearsal.json"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, name))
