@@ -610,13 +610,16 @@ __device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M
 
 // Every job of the launch: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
 // (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
-__global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* __restrict__ jobs, int tiles_x, int n_tiles, int lds_bytes)
+__global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* __restrict__ jobs, int tiles_x, int n_tiles, int lds_bytes, int run)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     const WarpJobDev& jb = jobs[blockIdx.y];
-    // block -> tile in raster order (a map that hands an XCD runs of 2, 4 or 8 x-adjacent tiles, so that the 192-byte row segments
-    // of neighbours meet in one L2, measured no better on the 4000 x 3000 tiles and 10 % worse on the 1241 x 376 frames)
-    const int t = blockIdx.x;
+    // block -> tile: linear block ids b, b + 8 share an XCD (and its L2); an XCD takes `run` x-adjacent tiles in a row, so that the
+    // source boxes and the 192-byte row segments of neighbouring tiles meet in one L2 (run = 4 on wide destinations: 1.15 instead of
+    // 1.38 times the algorithmic bytes on the 4000 x 3000 tiles at the same speed; run = 1, raster order, on narrow ones: the
+    // 1241 x 376 frames are 10 % faster that way -- profiles/r03_warp/README.md).  `run` is a power of two, the grid a multiple of 8 run.
+    const int b = blockIdx.x, r = b & (8 * run - 1);
+    const int t = (b - r) + (r & 7) * run + (r / 8);
     if (t >= n_tiles) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tx0 = tx * kTileW, ty0 = ty * kTileH;
@@ -1067,10 +1070,11 @@ hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max
         const int tiles_x = (max_dw + kTileW - 1) / kTileW;
         const long long n_tiles = (long long)tiles_x * ((max_dh + kTileH - 1) / kTileH);
         if (n_tiles < (1LL << 30)) {
-            dim3 tgrid((unsigned)n_tiles, n_jobs, 1);
+            const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
+            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp), n_jobs, 1);
             int lds = (std::max(tile_lds, 1024) + 255) & ~255;               // a wave's slice; behind it the wave's tie list (256 B)
             if (const char* e = getenv("DR3HIP_TILE_LDS")) lds = atoi(e);      // experiments only
-            hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds);
+            hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds, run);
             return hipGetLastError();
         }
     }

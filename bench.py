@@ -207,7 +207,7 @@ def newest_profile(fname, want_hash=None):
     return None, None
 
 
-def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json"):
+def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json", grid_threads=None):
     """HBM bytes per launch of one kernel from the newest committed PMC summary (profiles/*/pmc_traffic.json,
     made by tools/profile_bench.sh + tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same script; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).
@@ -218,7 +218,11 @@ def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json"):
         return None, None
     if j:
         for name, t in j.get("kernels", {}).items():
-            if kernel_substr in name and "hbm_bytes" in t:
+            if kernel_substr not in name:
+                continue
+            if grid_threads is not None:                     # a kernel that runs at several launch shapes: this one, or nothing
+                t = t.get("shapes", {}).get(str(int(grid_threads)), {})
+            if "hbm_bytes" in t:
                 return t["hbm_bytes"], src
     return None, None
 
@@ -1083,7 +1087,11 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
         alg = NT_ * TW_ * TH_ * 2 * esz                  # esz read + esz written per dst pixel
         plan = dr3.warp_plan(jobs[0], typ)
         kname = "warp_tile_8uc3_kernel" if plan["kernel"] == 2 else "warp_perspective_kernel<%d," % typ
-        traffic, tsrc = pmc_traffic(kname, 256, "pmc_traffic_warp.json")
+        if plan["kernel"] == 2:                              # the strip kernel's grid: 64 x 64 tiles x jobs x 256 threads
+            gthreads = -(-TW_ // 64) * -(-TH_ // 64) * NT_ * 256
+        else:                                                # the direct kernel: 64 x 4 pixels per 256-thread block, one pixel per lane
+            gthreads = -(-TW_ // 64) * -(-TH_ // 4) * NT_ * 256
+        traffic, tsrc = pmc_traffic(kname, 256, "pmc_traffic_warp.json", gthreads)
         res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms, "verified_vs_oracle": ok, "kernel_plan": plan,
                      "roofline": {"kernel": ("warp_tile_8uc3_kernel (LDS-staged strips)" if plan["kernel"] == 2 else "warp_perspective_kernel<%s>" % name.upper()), "bound": "hbm",
                                   "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -1238,7 +1246,9 @@ def kitti_warp_leg(dist, ctx, dr3, synth, sync, tile, steps):
             "kernel_plan": dr3.warp_plan(jobs[3], dr3.T_8UC3),
             "roofline": {"kernel": "warp_tile_8uc3_kernel (LDS-staged strips)" if dr3.warp_plan(jobs[3], dr3.T_8UC3)["kernel"] == 2 else "warp_perspective_kernel<8UC3>",
                          "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic("warp_tile_8uc3_kernel", 256, "pmc_traffic_warp.json", -(-W_ // 64) * -(-H_ // 64) * NJ * 256)[0]
+                                    if dr3.warp_plan(jobs[3], dr3.T_8UC3)["kernel"] == 2 else None,
                          "algorithmic_bytes_per_launch": alg}}
 
 

@@ -83,6 +83,14 @@ def main():
                    re.search(r"Depth=2", " ".join(x for x in body[i:i + 8] if x.startswith(".LBB") or x.strip().startswith(";")))), default=-1)
     # the end of that last depth-2 block: the next label
     tail_from = next((i for i in range(last_d2 + 1, len(body)) if re.match(r"^\.LBB\d+_\d+:", body[i])), len(body)) if last_d2 >= 0 else len(body)
+    # The compiler peels the first Gauss-Newton iteration of a level out of the iteration loop: the copy sits in the level loop (depth 1)
+    # in front of the loop proper and runs once per level.  It is the only code in front of the first depth-2 block that reads LDS (the
+    # template comes from global memory), which is how it is recognised; the loop proper then runs (iteration-levels - levels) times.
+    first_d2 = next((i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l) and
+                     re.search(r"Depth=2", " ".join(x for x in body[i:i + 8] if x.startswith(".LBB") or x.strip().startswith(";")))), len(body))
+    peeled = any(re.match(r"\s*ds_read", l) for l in body[:first_d2])
+    if peeled:
+        w_of_depth[2] = max(0.0, iter_levels - levels)
     tot = {"fast": 0.0, "std": 0.0, "trans": 0.0}
     static = {"fast": 0, "std": 0, "trans": 0}
     cur_depth = 0
@@ -109,7 +117,8 @@ def main():
     cycles = 2 * tot["fast"] + 4 * tot["std"] + 8 * tot["trans"]
     dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
     out = {"kernel": m.group(1), "kernel_demangled": dem, "source_hash": source_hash(),
-           "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0, "level_loop_tail_behind_the_iterations": 1.0},
+           "weights": {"levels": levels, "iteration_levels_per_wave": iter_levels, "deeper_loops": 0.0, "level_loop_tail_behind_the_iterations": 1.0,
+                       "first_iteration_peeled_into_the_level_loop": bool(peeled), "iteration_loop_proper": w_of_depth[2]},
            "measured_valu_per_wave": measured, "predicted_over_measured": None if not measured else round(n / measured, 4),
            "static_valu": static, "weighted_valu_per_wave": {k: round(v, 1) for k, v in tot.items()},
            "weighted_valu_per_wave_total": round(n, 1), "issue_clocks_per_wave": round(cycles, 1),

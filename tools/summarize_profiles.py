@@ -143,19 +143,27 @@ def main(src, dst):
         p = os.path.join(src, sub, stem + "_counter_collection.csv")
         if not os.path.exists(p):
             continue
-        for k, v in per_kernel(p, counter, largest_grid_only=True).items():
-            t = wt.setdefault(k, {})
+        shapes = {}                                          # (kernel, grid threads) -> values: a kernel runs at several launch shapes
+        for row in csv.DictReader(open(p, newline="")):
+            if row["Counter_Name"] == counter:
+                shapes.setdefault((row["Kernel_Name"], int(row["Grid_Size"])), []).append(float(row["Counter_Value"]))
+        for (k, g), v in shapes.items():
+            t = wt.setdefault(k, {"shapes": {}})["shapes"].setdefault(str(g), {"dispatches": len(v)})
             kb = statistics.median(v)
             if counter == "FETCH_SIZE":
                 t["fetch_bytes_raw"] = kb * 1024.0
                 t["fetch_bytes"] = kb * 1024.0 * 2.0
             else:
                 t["write_bytes"] = kb * 1024.0
-    for k, t in wt.items():
-        if "fetch_bytes" in t and "write_bytes" in t:
-            t["hbm_bytes"] = t["fetch_bytes"] + t["write_bytes"]
+    for k, e in wt.items():
+        for g, t in e["shapes"].items():
+            if "fetch_bytes" in t and "write_bytes" in t:
+                t["hbm_bytes"] = t["fetch_bytes"] + t["write_bytes"]
+        big = max(e["shapes"], key=int)                      # top-level fields: the largest launch shape of the kernel
+        e.update({kk: vv for kk, vv in e["shapes"][big].items() if kk != "dispatches"}); e["grid_threads"] = int(big)
     if wt:
-        json.dump({"note": "bytes per launch of the configs[2] launch shape (the largest dispatch of each kernel in tools/warp_quick.py); "
+        json.dump({"note": "bytes per launch of the kernels of tools/warp_quick.py, per launch shape (`shapes`, keyed by grid threads) -- a kernel "
+                           "runs at several: the configs[2] tiles, the KITTI-sized frames -- and, at top level, of the largest one; "
                            "FETCH_SIZE doubled (gfx950)", "source_hash": source_hash(TRAFFIC_HASH_FILES),
                    "kernels": wt}, open(os.path.join(dst, "pmc_traffic_warp.json"), "w"), indent=1)
 
