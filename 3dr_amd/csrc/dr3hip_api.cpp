@@ -60,9 +60,9 @@ struct dr3hip_batch {
     void* der_base[DR3HIP_MAX_LEVELS] = {nullptr};
     size_t bytes = 0;
     // detector storage (dr3hip_batch_detect), allocated on first use: half-sample pyramid levels 1.. of every
-    // slot (continuous rows like the reference's cv::Mat levels), one score map and one cell-key array per slot
+    // slot (continuous rows like the reference's cv::Mat levels) and one cell-key array per slot
     struct Det { int n_levels = 0, n_cells = 0; uint8_t* hs[8] = {nullptr}; long long hs_step[8] = {0};
-                 uint8_t* score = nullptr; long long score_step = 0; int spitch = 0; unsigned long long* keys = nullptr; } det;
+                 unsigned long long* keys = nullptr; } det;
 };
 
 static std::string g_init_err;
@@ -360,7 +360,7 @@ int dr3hip_fast_score_map(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int
     a.score = (uint8_t*)ctx->stage[1].p; a.spitch = ip; a.threshold = fast_threshold;
     a.level = 0; a.cell_size = 1; a.grid_cols = 1; a.det_threshold = 0.f; a.occupancy = nullptr; a.cells = nullptr;
     a.n_slots = 1; a.img_step = 0; a.score_step = 0; a.n_cells = 0;
-    HIPCHK(ctx, launch_fast_score(a, ctx->stream));
+    HIPCHK(ctx, launch_fast_level(a, ctx->stream));
     { const int rc2_ = copy2d_d2h(ctx, score_map, w, a.score, ip, w, h); if (rc2_) return rc2_; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return DR3HIP_OK;
@@ -390,9 +390,8 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
         off[l] = total;
         total += (size_t)align_up((long long)lp[l] * lh[l] + 64, 256ll);
     }
-    const int sp = align_up(w, 64);
     const size_t cells_off = (size_t)align_up(n_cells, 256);          // stage[6]: occupancy bytes, then the cell keys
-    if ((rc = stage_reserve(ctx, 4, total)) || (rc = stage_reserve(ctx, 1, (size_t)sp * h + 256)) ||
+    if ((rc = stage_reserve(ctx, 4, total)) ||
         (rc = stage_reserve(ctx, 6, cells_off + sizeof(unsigned long long) * (size_t)n_cells))) return rc;
     uint8_t* base = (uint8_t*)ctx->stage[4].p;
     uint8_t* d_occ = (uint8_t*)ctx->stage[6].p;
@@ -410,12 +409,11 @@ int dr3hip_fast_detect(dr3hip_ctx* ctx, const uint8_t* img, int w, int h, int st
     for (int l = 0; l < n_levels; ++l) {
         FastArgs a;
         a.img = base + off[l]; a.w = lw[l]; a.h = lh[l]; a.stride = lp[l];
-        a.score = (uint8_t*)ctx->stage[1].p; a.spitch = sp; a.threshold = fast_threshold;
+        a.score = nullptr; a.spitch = 0; a.threshold = fast_threshold;                  // no score map: the kernel keeps the scores in LDS
         a.level = l; a.cell_size = cell_size; a.grid_cols = gc; a.det_threshold = thr_f;
         a.occupancy = occupancy ? d_occ : nullptr; a.cells = d_cells;
         a.n_slots = 1; a.img_step = 0; a.score_step = 0; a.n_cells = n_cells;
-        HIPCHK(ctx, launch_fast_score(a, ctx->stream));
-        HIPCHK(ctx, launch_fast_select(a, ctx->stream));
+        HIPCHK(ctx, launch_fast_level(a, ctx->stream));
     }
     prof_end(ctx, pe);
     std::vector<unsigned long long> keys((size_t)n_cells);
@@ -462,7 +460,6 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
     if (D.n_levels < n_levels || D.n_cells < n_cells) {               // (re)allocate the detector storage
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (int l = 0; l < 8; ++l) if (D.hs[l]) { (void)hipFree(D.hs[l]); D.hs[l] = nullptr; }
-        if (D.score) { (void)hipFree(D.score); D.score = nullptr; }
         if (D.keys) { (void)hipFree(D.keys); D.keys = nullptr; }
         D.n_levels = 0; D.n_cells = 0;
         int lw = w, lh = h;
@@ -473,16 +470,11 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
             if (hipMalloc(&p, (size_t)D.hs_step[l] * b->capacity + 256) != hipSuccess) return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (level %d)", l);
             D.hs[l] = (uint8_t*)p; b->bytes += (size_t)D.hs_step[l] * b->capacity + 256;
         }
-        D.spitch = align_up(w, 64);
-        D.score_step = align_up((long long)D.spitch * h, 256ll);
-        void *ps = nullptr, *pk = nullptr;
-        if (hipMalloc(&ps, (size_t)D.score_step * b->capacity + 256) != hipSuccess ||
-            hipMalloc(&pk, sizeof(unsigned long long) * (size_t)n_cells * b->capacity) != hipSuccess) {
-            if (ps) (void)hipFree(ps);
-            return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (score map / cells)");
-        }
-        D.score = (uint8_t*)ps; D.keys = (unsigned long long*)pk;
-        b->bytes += (size_t)D.score_step * b->capacity + 256 + sizeof(unsigned long long) * (size_t)n_cells * b->capacity;
+        void* pk = nullptr;
+        if (hipMalloc(&pk, sizeof(unsigned long long) * (size_t)n_cells * b->capacity) != hipSuccess)
+            return fail(ctx, DR3HIP_ENOMEM, "batch_detect: hipMalloc (cells)");
+        D.keys = (unsigned long long*)pk;
+        b->bytes += sizeof(unsigned long long) * (size_t)n_cells * b->capacity;
         D.n_levels = n_levels; D.n_cells = n_cells;
     }
     // cell keys: all-zero = still the initial Corner(0, 0, detection_threshold, 0) (src/features.cpp:49); the select
@@ -509,11 +501,10 @@ int dr3hip_batch_detect(dr3hip_batch* b, int first, int count, int n_levels, int
         a.img = (l == 0) ? b->lv[0].img + (size_t)b->lv[0].step * first : D.hs[l] + (size_t)D.hs_step[l] * first;
         a.w = lw; a.h = lh; a.stride = (l == 0) ? b->lv[0].pitch : lw;
         a.img_step = (l == 0) ? b->lv[0].step : D.hs_step[l];
-        a.score = D.score + (size_t)D.score_step * first; a.spitch = D.spitch; a.score_step = D.score_step;
+        a.score = nullptr; a.spitch = 0; a.score_step = 0;                                 // no score map: the kernel keeps the scores in LDS
         a.threshold = fast_threshold; a.level = l; a.cell_size = cell_size; a.grid_cols = gc; a.det_threshold = thr_f;
         a.occupancy = nullptr; a.cells = keys; a.n_slots = count; a.n_cells = n_cells;
-        HIPCHK(ctx, launch_fast_score(a, ctx->stream));
-        HIPCHK(ctx, launch_fast_select(a, ctx->stream));
+        HIPCHK(ctx, launch_fast_level(a, ctx->stream));
         lw /= 2; lh /= 2;
     }
     CellsArgs ca;
@@ -1065,7 +1056,6 @@ void dr3hip_batch_destroy(dr3hip_batch* b)
         if (b->der_base[l]) (void)hipFree(b->der_base[l]);
         if (b->det.hs[l]) (void)hipFree(b->det.hs[l]);
     }
-    if (b->det.score) (void)hipFree(b->det.score);
     if (b->det.keys) (void)hipFree(b->det.keys);
     if (b->ctx->lk_batch == b) b->ctx->lk_batch = nullptr;
     delete b;

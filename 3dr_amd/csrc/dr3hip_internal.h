@@ -103,12 +103,12 @@ struct PanoNormArgs {      // Panorama::normalize_canvas (src/panorama.cpp:215-2
 
 struct FastArgs {          // FAST-10 score map + grid-best selection of one pyramid level (fast_kernels.hip)
     const uint8_t* img; int w, h, stride;         // level image
-    uint8_t* score;     int spitch;               // u8 score map (0 = no corner)
+    uint8_t* score;     int spitch;               // u8 score map (0 = no corner), null: not wanted; spitch a multiple of 64 >= w
     int threshold;                                // FAST threshold (reference: 20)
     int level, cell_size, grid_cols;
     float det_threshold;                          // (float)detection_threshold: the initial Corner score of every cell
     const uint8_t* occupancy;                     // device, grid cells, may be null
-    unsigned long long* cells;                    // device, per cell: (score bits << 32) | ~raster order
+    unsigned long long* cells;                    // device, per cell: (score bits << 32) | ~raster order; null: score map only
     int n_slots;                                  // grid z: frames (0 or 1: a single image)
     long long img_step, score_step;               // bytes between frames
     int n_cells;                                  // cells (and occupancy bytes) per frame
@@ -201,11 +201,10 @@ constexpr int kWarpTileW = 64, kWarpTileH = 64, kWarpStripRows = 16;   // warp_t
 constexpr int kWarpTileLdsBytes = 15 * 1024;                          // the largest LDS slice of a wave (4 slices + tie lists <= 64 KiB)
 hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s);
 hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s);
-hipError_t launch_fast_score(const FastArgs& a, hipStream_t s);
+hipError_t launch_fast_level(const FastArgs& a, hipStream_t s);     // score (map if a.score) + selection (if a.cells) of one level
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s);
 hipError_t launch_sparse_align(const AlignArgs& a, int n_pairs, hipStream_t s);
-hipError_t launch_fast_select(const FastArgs& a, hipStream_t s);
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);

@@ -3,14 +3,13 @@
 // utils::shi_tomasi_score src/utils.cpp:282-321) for gfx950.  SURVEY 8f.2: this is what produces the
 // points the LK tracker consumes.  The `fast` library the reference links (CMakeLists.txt:17) is not
 // vendored; its published algorithm is restated here ("FAST"), parity unpinned.
-//   fast10_score_kernel : one lane per 4 pixels (compass quick-rejection from dword loads).  The library finds the score by bisection over the corner
-//                         test; the fixed point of that search has a closed form -- the largest b for which
-//                         10 contiguous ring pixels are all > p + b (or all < p - b) is
+//   fast_tile_kernel    : one workgroup per 64 x 32 tile of a level, all phases out of LDS (see the kernel).  The library finds
+//                         the score by bisection over the corner test; the fixed point of that search has a closed form -- the
+//                         largest b for which 10 contiguous ring pixels are all > p + b (or all < p - b) is
 //                         max over the 16 arcs of min over the arc of (ring - p) (resp. p - ring), minus 1 --
 //                         evaluated with a doubling sliding minimum (windows 2, 4, 8, 10).  A pixel is a
-//                         corner at threshold t iff that score is >= t.
-//   fast_select_kernel  : one lane per 8 bytes of the score map; per corner: 3x3 non-max (a corner falls when an adjacent
-//                         corner scores >= it), occupancy test, Shi-Tomasi score of the 8x8 box (integer
+//                         corner at threshold t iff that score is >= t.  Then per corner: 3x3 non-max (a corner falls when
+//                         an adjacent corner scores >= it), occupancy test, Shi-Tomasi score of the 8x8 box (integer
 //                         sums are exact in the reference's f32 accumulators: 64 * 255^2 < 2^24), then a
 //                         64-bit atomicMax per grid cell on (score bits, ~raster order): the reference keeps
 //                         the first corner of the best score in level-major raster order.
@@ -58,151 +57,208 @@ __device__ __forceinline__ int ballot_rank(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// A wave owns 256 pixels of one row, a lane 4 adjacent ones (x % 4 == 0).
-//  1. Rosten's quick rejection: any 10 contiguous ring pixels contain at least two of the four compass pixels (ring
-//     positions 0, 4, 8, 12), so a corner at threshold t needs two of them > c + t or two < c - t.  The compass pixels
-//     of the lane's 4 pixels come from five aligned dword loads (rows y - 3, y + 3: one dword; row y: bytes x-4 .. x+7).
-//  2. The few survivors are compacted through LDS (ballot + mbcnt) so that the 16-pixel ring score runs on densely
-//     packed lanes -- once per 64 candidates instead of once per pixel slot with any candidate in the wave.
-//  3. Each lane collects its 4 result bytes from LDS and stores one dword of the score map.
-__global__ __launch_bounds__(256) void fast10_score_kernel(const FastArgs a)
+// utils::shi_tomasi_score, reference src/utils.cpp:282-321, from the integer sums of the 8 x 8 box (exact in the reference's f32
+// accumulators: 64 * 255^2 < 2^24)
+__device__ __forceinline__ float shi_tomasi_from_sums(int sxx, int syy, int sxy)
 {
-    __shared__ uint16_t s_cand[4][256];
-    __shared__ uint32_t s_res[4][64];
-    const int lane = threadIdx.x, wv = threadIdx.y;
-    const int xw = blockIdx.x * 256;
-    const int x = xw + lane * 4;
-    const int y = blockIdx.y * 4 + wv;
-    if (xw >= a.w || y >= a.h) return;                                   // wave-uniform
-    const uint8_t* __restrict__ img = a.img + (long long)blockIdx.z * a.img_step;
-    const uint8_t* row = img + (long long)y * a.stride;
-    const int t = a.threshold;
-    uint32_t cand = 0;                                                    // bit k: pixel x + k passed the quick test
-    if (y >= 3 && y < a.h - 3 && x < a.w) {                              // fast_corner_detect_10 scans [3, size - 3)
-        const bool wide = x >= 4 && x + 8 <= a.stride && (((uintptr_t)img | (uintptr_t)a.stride) & 3) == 0;   // dword loads stay in the row
-        uint32_t up = 0, dn = 0, lo = 0, mid = 0, hi = 0;
-        if (wide) {
-            up = *reinterpret_cast<const uint32_t*>(row - 3 * a.stride + x);
-            dn = *reinterpret_cast<const uint32_t*>(row + 3 * a.stride + x);
-            lo = *reinterpret_cast<const uint32_t*>(row + x - 4);
-            mid = *reinterpret_cast<const uint32_t*>(row + x);
-            hi = *reinterpret_cast<const uint32_t*>(row + x + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int xx = x + k;
-            if (xx < 3 || xx >= a.w - 3) continue;
-            int c, n0, n4, n8, n12;
-            if (wide) {
-                const uint64_t rowbits = ((uint64_t)hi << 32) | mid;    // bytes x .. x + 7
-                const uint64_t lobits = ((uint64_t)mid << 32) | lo;     // bytes x - 4 .. x + 3
-                c = (mid >> (8 * k)) & 0xff;
-                n0 = (int)((dn >> (8 * k)) & 0xff) - c;                 // ring 0:  (0, +3)
-                n8 = (int)((up >> (8 * k)) & 0xff) - c;                 // ring 8:  (0, -3)
-                n4 = (int)((rowbits >> (8 * (k + 3))) & 0xff) - c;      // ring 4:  (+3, 0)
-                n12 = (int)((lobits >> (8 * (k + 1))) & 0xff) - c;      // ring 12: (-3, 0)
-            } else {
-                const uint8_t* p = row + xx;
-                c = p[0]; n0 = (int)p[3 * a.stride] - c; n4 = (int)p[3] - c; n8 = (int)p[-3 * a.stride] - c; n12 = (int)p[-3] - c;
-            }
-            const int nb = (n0 > t) + (n4 > t) + (n8 > t) + (n12 > t), nd = (n0 < -t) + (n4 < -t) + (n8 < -t) + (n12 < -t);
-            if (nb >= 2 || nd >= 2) cand |= 1u << k;
-        }
-    }
-    // compaction: candidate (lane, k) -> dense slot
-    s_res[wv][lane] = 0u;
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool c = (cand >> k) & 1u;
-        const unsigned long long m = __ballot(c);
-        if (c) s_cand[wv][total + ballot_rank(m)] = (uint16_t)(4 * lane + k);
-        total += __popcll(m);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint8_t* res8 = reinterpret_cast<uint8_t*>(s_res[wv]);
-    for (int i = lane; i < total; i += 64) {
-        const int idx = s_cand[wv][i];
-        const uint8_t* p = row + xw + idx;
-        const int score = ring_score(p, a.stride, p[0]);
-        if (score >= t) res8[idx] = (uint8_t)score;                     // <= 254
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (x < a.w) {
-        uint8_t* orow = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch + x;
-        *reinterpret_cast<uint32_t*>(orow) = s_res[wv][lane];           // spitch is a multiple of 64 >= w: pad bytes become 0
-    }
-}
-
-// utils::shi_tomasi_score, reference src/utils.cpp:282-321
-__device__ float shi_tomasi(const uint8_t* __restrict__ img, int w, int h, int stride, int u, int v)
-{
-    const int x_min = u - 4, x_max = u + 4, y_min = v - 4, y_max = v + 4;
-    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.f;
-    int sxx = 0, syy = 0, sxy = 0;                                    // exact: each fits 23 bits
-    for (int y = y_min; y < y_max; ++y) {
-        const uint8_t* r = img + (long long)y * stride + x_min;
-        for (int x = 0; x < 8; ++x) {
-            const int dx = (int)r[x + 1] - (int)r[x - 1];
-            const int dy = (int)r[x + stride] - (int)r[x - stride];
-            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
-        }
-    }
     const float dXX = (float)((double)(float)sxx / 128.0), dYY = (float)((double)(float)syy / 128.0), dXY = (float)((double)(float)sxy / 128.0);
     const float t = dXX + dYY;
     const float disc = t * t - 4.f * (dXX * dYY - dXY * dXY);
     return (float)(0.5 * ((double)t - sqrt((double)disc)));
 }
 
-// one surviving corner of the score map: non-max test, occupancy, Shi-Tomasi, per-cell atomicMax
-__device__ void select_pixel(const FastArgs& a, const uint8_t* __restrict__ sp, int x, int y, int s, int z)
+// One workgroup decides a kFtW x kFtH tile of one pyramid level of one frame, everything out of LDS:
+//  0. the image tile with a border of 5 rows / 8 columns (ring radius 3 + the neighbour ring of the non-maximum test + the
+//     Shi-Tomasi box) is staged with one dword load per lane and round -- byte-aligned, the half-sampled levels have odd pitches;
+//  1. Rosten's quick rejection on every pixel of the tile and of the one-pixel ring around it (whose scores the non-maximum test
+//     of the tile's edge needs), a lane per 4 adjacent pixels: any 10 contiguous ring pixels contain two of the four compass
+//     pixels (ring positions 0, 4, 8, 12), so a corner at threshold t needs two of them > c + t or two < c - t -- i.e. the
+//     second largest compass value > c + t or the second smallest < c - t (a 4-input sorting network of v_min / v_max instead of
+//     eight compares).  Survivors are appended to an LDS list (ballot + mbcnt, one LDS atomic per wave and round);
+//  2. the 16-pixel ring score of the listed pixels on densely packed lanes, written to a byte score tile in LDS
+//     (and, when the caller wants the score map, from there to memory);
+//  3. per listed corner of the tile proper: 3 x 3 non-maximum test on the score tile (a corner falls when an adjacent corner scores
+//     >= it), image-border test of the Shi-Tomasi box, occupancy; the few survivors go to a second list;
+//  4. Shi-Tomasi score of the 8 x 8 box out of the image tile, then a 64-bit atomicMax per grid cell on (score bits, ~raster
+//     order): the reference keeps the first corner of the best score in level-major raster order.
+// No score map is written or read back on the detector's path, and the image is read once.
+constexpr int kFtW = 64, kFtH = 32;                        // pixels a workgroup decides
+constexpr int kFiPitch = 80, kFiRows = kFtH + 10;          // image tile: columns x0 - 8 .. x0 + 71, rows y0 - 5 .. y0 + kFtH + 4
+constexpr int kFsPitch = 72, kFsRows = kFtH + 2;           // score tile: columns x0 - 4 .. x0 + 67, rows y0 - 1 .. y0 + kFtH
+constexpr int kFsGroups = kFsPitch / 4;                    // 4-pixel groups of a score row
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// sum over the 8 lanes of an aligned group (DPP: xor 1, xor 2, then the half-row mirror, which is xor 4 once the quads are uniform)
+__device__ __forceinline__ int sum8(int v)
 {
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            if ((dx | dy) == 0) continue;
-            const int xx = x + dx, yy = y + dy;
-            if (xx < 0 || xx >= a.w || yy < 0 || yy >= a.h) continue;
-            const int t = sp[dy * a.spitch + dx];
-            if (t > 0 && t >= s) return;                              // fast_nonmax_3x3
-        }
-    const int scale = 1 << a.level;
-    const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
-    if (a.occupancy && a.occupancy[(long long)z * a.n_cells + k]) return;
-    const float score = shi_tomasi(a.img + (long long)z * a.img_step, a.w, a.h, a.stride, x, y);
-    if (!(score > a.det_threshold)) return;                           // can never beat the cell's initial Corner
-    const uint32_t order = ((uint32_t)a.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)~order;
-    atomicMax(a.cells + (long long)z * a.n_cells + k, key);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    return v;
+}
+// LDS fetch-and-add with a per-lane addend, as the one instruction it is: the compiler's atomic optimizer would turn the divergent
+// addend into a loop over the active lanes (some 50 instructions per lane), which is the wrong trade when most lanes take part
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* counter, uint32_t v)
+{
+    uint32_t old;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)counter;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+    return old;
+}
+// per 16-bit lane: non-zero iff the second largest of (a, b, c, d) > ctr + t or the second smallest < ctr - t (all values <= 255)
+__device__ __forceinline__ u16x2 second_extremes_beyond(u16x2 a, u16x2 b, u16x2 c, u16x2 d, u16x2 ctr, u16x2 t)
+{
+    const u16x2 h1 = __builtin_elementwise_max(a, b), l1 = __builtin_elementwise_min(a, b);
+    const u16x2 h2 = __builtin_elementwise_max(c, d), l2 = __builtin_elementwise_min(c, d);
+    const u16x2 A = __builtin_elementwise_min(h1, h2), B = __builtin_elementwise_max(l1, l2);
+    const u16x2 s2l = __builtin_elementwise_max(A, B), s2s = __builtin_elementwise_min(A, B);
+    const u16x2 hi = ctr + t, lo = __builtin_elementwise_sub_sat(ctr, t);              // c - t < 0: nothing is darker
+    return __builtin_elementwise_sub_sat(s2l, hi) | __builtin_elementwise_sub_sat(lo, s2s);
 }
 
-// scan of the score map: a wave owns 512 map bytes of one row, a lane 8 of them (rows are 64-byte pitched); the corners
-// found are compacted through LDS so that the non-max test and the 8x8 Shi-Tomasi box run on densely packed lanes
-__global__ __launch_bounds__(256) void fast_select_kernel(const FastArgs a)
+__global__ __launch_bounds__(256) void fast_tile_kernel(const FastArgs a)
 {
-    __shared__ uint16_t s_list[4][512];
-    const int lane = threadIdx.x, wv = threadIdx.y;
-    const int xw = blockIdx.x * 512;
-    const int x = xw + lane * 8;
-    const int y = blockIdx.y * 4 + wv;
-    if (xw >= a.w || y >= a.h) return;                                   // wave-uniform
-    const uint8_t* srow = a.score + (long long)blockIdx.z * a.score_step + (long long)y * a.spitch;
-    uint2 v = make_uint2(0u, 0u);
-    if (x < a.w) v = *reinterpret_cast<const uint2*>(srow + x);
-    if (__ballot((v.x | v.y) != 0) == 0ull) return;                     // nothing in these 512 bytes
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool c = (((k < 4 ? v.x : v.y) >> (8 * (k & 3))) & 0xff) != 0 && x + k < a.w;
-        const unsigned long long m = __ballot(c);
-        if (c) s_list[wv][total + ballot_rank(m)] = (uint16_t)(8 * lane + k);
-        total += __popcll(m);
+    __shared__ uint32_t s_img[kFiRows * kFiPitch / 4];
+    __shared__ uint32_t s_score[kFsRows * kFsPitch / 4];
+    __shared__ uint16_t s_cand[kFsRows * kFsPitch];          // (score row << 7) | score column
+    __shared__ uint16_t s_surv[kFtW * kFtH];
+    __shared__ uint32_t s_n[2];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH, z = blockIdx.z;
+    const uint8_t* __restrict__ img = a.img + (long long)z * a.img_step;
+    const int t = a.threshold;
+
+    // ---- 0. clear the score tile, stage the image tile: 16 bytes per lane, one round (pixels outside the image are never used) ----
+    for (int i = tid; i < kFsRows * kFsPitch / 16; i += 256) reinterpret_cast<uint4*>(s_score)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2) s_n[tid] = 0u;
+    if (tid < kFiRows * (kFiPitch / 16)) {
+        const int row = (tid * 13108) >> 16, j = tid - row * (kFiPitch / 16);         // tid / 5, tid % 5
+        const int gy = y0 - 5 + row, gx = x0 - 8 + 16 * j;                            // gx < 0 only as -8 (first tile of a row, j = 0)
+        const bool ok = (unsigned)gy < (unsigned)a.h && gx < a.w;                     // the 16 bytes may run past w: row padding / slack
+        u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned*>(img + (ok ? gy * a.stride + max(gx, 0) : 0));
+        if (gx < 0) v = u32x4_unaligned{0u, 0u, v.x, v.y};
+        if (!ok) v = u32x4_unaligned{0u, 0u, 0u, 0u};
+        reinterpret_cast<u32x4_lds*>(s_img)[tid] = v;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < total; i += 64) {
-        const int xx = xw + s_list[wv][i];
-        select_pixel(a, srow + xx, xx, y, srow[xx], blockIdx.z);
+    __syncthreads();
+
+    // ---- 1. quick rejection, a lane per 4 pixels of the score tile, in packed 16-bit lanes: E holds pixels 0 and 2, O pixels 1, 3 ----
+    constexpr int kRounds = (kFsRows * kFsGroups + 255) / 256;
+    static_assert(kRounds <= 8, "the candidate mask of a lane has 2 x 16 bits");
+    const u16x2 T2 = {(uint16_t)t, (uint16_t)t}, ONE2 = {1, 1};
+    uint32_t mask = 0;                    // round r, pixel k of the lane's group: bit 2 r + (k & 1) + 16 (k >> 1)
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int i = tid + 256 * r;
+        const int row = (i * 3641) >> 16, j = i - row * kFsGroups;                     // i / 18, i % 18
+        const int y = y0 - 1 + row;
+        if (i < kFsRows * kFsGroups && y >= 3 && y < a.h - 3) {                        // fast_corner_detect_10 scans [3, size - 3)
+            const uint32_t* p = s_img + (row + 4) * (kFiPitch / 4) + j + 1;
+            const uint32_t up = p[-3 * (kFiPitch / 4)], dn = p[3 * (kFiPitch / 4)], lo = p[-1], mid = p[0], hi = p[1];
+            const uint32_t M = 0x00ff00ffu;
+            const u16x2 cE = as_u16x2(mid & M), cO = as_u16x2((mid >> 8) & M);
+            const u16x2 n0E = as_u16x2(dn & M), n0O = as_u16x2((dn >> 8) & M);         // ring 0:  (0, +3)
+            const u16x2 n8E = as_u16x2(up & M), n8O = as_u16x2((up >> 8) & M);         // ring 8:  (0, -3)
+            // ring 4 (+3, 0): bytes 3 .. 6 of (mid, hi);  ring 12 (-3, 0): bytes 1 .. 4 of (lo, mid)
+            const u16x2 n4E = as_u16x2(__builtin_amdgcn_perm(hi, mid, 0x0c050c03u)), n4O = as_u16x2(hi & M);
+            const u16x2 n12E = as_u16x2((lo >> 8) & M), n12O = as_u16x2(__builtin_amdgcn_perm(mid, lo, 0x0c040c02u));
+            // a corner needs two compass pixels > c + t or two < c - t: the second largest above c + t or the second smallest below c - t
+            const u16x2 rE = __builtin_elementwise_min(second_extremes_beyond(n0E, n4E, n8E, n12E, cE, T2), ONE2);
+            const u16x2 rO = __builtin_elementwise_min(second_extremes_beyond(n0O, n4O, n8O, n12O, cO, T2), ONE2);
+            mask |= (as_u32(rE) | (as_u32(rO) << 1)) << (2 * r);
+        }
+    }
+    // the lane's candidates of all rounds go to the list behind one LDS fetch-and-add; columns outside [3, w - 3) are dropped here
+    if (mask) {
+        uint32_t keep = mask;
+        if (x0 < 8 || x0 + kFsPitch > a.w - 3) {                                       // only the first and the last tiles of a row hold such columns
+            keep = 0;
+            for (uint32_t m = mask; m; m &= m - 1) {
+                const int b = __builtin_ctz(m), r = (b & 15) >> 1, k = (b & 1) | ((b >> 4) << 1);
+                const int i = tid + 256 * r, row = (i * 3641) >> 16, j = i - row * kFsGroups;
+                const int x = x0 - 4 + 4 * j + k;
+                if (x >= 3 && x < a.w - 3) keep |= 1u << b;
+            }
+        }
+        if (keep) {
+            uint32_t pos = lds_add_rtn(&s_n[0], (uint32_t)__popc(keep));
+            for (uint32_t m = keep; m; m &= m - 1) {
+                const int b = __builtin_ctz(m), r = (b & 15) >> 1, k = (b & 1) | ((b >> 4) << 1);
+                const int i = tid + 256 * r, row = (i * 3641) >> 16, j = i - row * kFsGroups;
+                s_cand[pos++] = (uint16_t)((row << 7) | (4 * j + k));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. ring scores of the listed pixels ----
+    const int ncand = (int)s_n[0];
+    uint8_t* sc8 = reinterpret_cast<uint8_t*>(s_score);
+    const uint8_t* im8 = reinterpret_cast<const uint8_t*>(s_img);
+    for (int i = tid; i < ncand; i += 256) {
+        const int e = s_cand[i], sr = e >> 7, sx = e & 127;
+        const uint8_t* p = im8 + (sr + 4) * kFiPitch + sx + 4;
+        const int score = ring_score(p, kFiPitch, p[0]);
+        if (score >= t) sc8[sr * kFsPitch + sx] = (uint8_t)score;                      // <= 254
+    }
+    __syncthreads();
+    if (a.score) {                                                                     // the caller wants the map: rows of 64 bytes, 0 = no corner
+        uint8_t* sm = a.score + (long long)z * a.score_step;
+        for (int i = tid; i < kFtH * (kFtW / 4); i += 256) {
+            const int r = i >> 4, jj = i & 15, y = y0 + r;
+            if (y < a.h) *reinterpret_cast<uint32_t*>(sm + (long long)y * a.spitch + x0 + 4 * jj) = s_score[(r + 1) * kFsGroups + 1 + jj];
+        }                                                                              // spitch is a multiple of 64 >= w: pad bytes become 0
+    }
+    if (!a.cells || ncand == 0) return;
+
+    // ---- 3. non-maximum test, image border of the Shi-Tomasi box, occupancy ----
+    for (int i = tid; i < ncand; i += 256) {
+        const int e = s_cand[i], sr = e >> 7, sx = e & 127;
+        if (sr < 1 || sr > kFtH || sx < 4 || sx >= 4 + kFtW) continue;                 // the ring around the tile belongs to the neighbours
+        const uint8_t* q = sc8 + sr * kFsPitch + sx;
+        const int s = q[0];
+        if (s == 0) continue;
+        // fast_nonmax_3x3: a neighbour that is a corner (score > 0) and scores >= s removes this one; pixels outside the image hold 0
+        const int nmax = max(max(max((int)q[-kFsPitch - 1], (int)q[-kFsPitch]), max((int)q[-kFsPitch + 1], (int)q[-1])),
+                             max(max((int)q[1], (int)q[kFsPitch - 1]), max((int)q[kFsPitch], (int)q[kFsPitch + 1])));
+        if (nmax >= s) continue;
+        const int x = x0 - 4 + sx, y = y0 - 1 + sr;
+        // utils::shi_tomasi_score returns 0 when the box leaves the image: never above the cell's initial Corner (threshold >= 0)
+        if (x - 4 < 1 || x + 4 >= a.w - 1 || y - 4 < 1 || y + 4 >= a.h - 1) continue;
+        const int scale = 1 << a.level;
+        const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
+        if (a.occupancy && a.occupancy[(long long)z * a.n_cells + k]) continue;
+        s_surv[atomicAdd(&s_n[1], 1u)] = (uint16_t)e;
+    }
+    __syncthreads();
+
+    // ---- 4. Shi-Tomasi of the survivors, eight lanes per corner (a row of the 8 x 8 box each), per-cell winner ----
+    const int nsurv = (int)s_n[1];
+    const int sub = tid & 7;
+    for (int i0 = 0; i0 < nsurv; i0 += 32) {                                           // wave-uniform trip count
+        const int i = i0 + (tid >> 3);
+        const int e = i < nsurv ? s_surv[i] : ((1 << 7) | 4), sr = e >> 7, sx = e & 127;   // idle lanes read a valid address
+        const uint8_t* b = im8 + (sr + 4 - 5 + sub) * kFiPitch + (sx + 4 - 5);         // pixel (y - 5 + sub, x - 5); the lane's box row is the next one
+        int sxx = 0, syy = 0, sxy = 0;                                                 // exact: each fits 23 bits, so the order of the sums is free
+#pragma unroll
+        for (int xx = 0; xx < 8; ++xx) {
+            const int dx = (int)b[kFiPitch + xx + 2] - (int)b[kFiPitch + xx];
+            const int dy = (int)b[2 * kFiPitch + xx + 1] - (int)b[xx + 1];
+            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+        }
+        sxx = sum8(sxx); syy = sum8(syy); sxy = sum8(sxy);
+        if (sub != 0 || i >= nsurv) continue;
+        const float score = shi_tomasi_from_sums(sxx, syy, sxy);
+        if (!(score > a.det_threshold)) continue;                                      // can never beat the cell's initial Corner
+        const int x = x0 - 4 + sx, y = y0 - 1 + sr;
+        const int scale = 1 << a.level;
+        const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;
+        const uint32_t order = ((uint32_t)a.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)~order;
+        atomicMax(a.cells + (long long)z * a.n_cells + k, key);
     }
 }
 
@@ -411,19 +467,11 @@ hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_fast_score(const FastArgs& a, hipStream_t s)
+hipError_t launch_fast_level(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 255) / 256, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
-    hipLaunchKernelGGL(fast10_score_kernel, grid, block, 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_fast_select(const FastArgs& a, hipStream_t s)
-{
-    if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((a.w + 511) / 512, (a.h + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
-    hipLaunchKernelGGL(fast_select_kernel, grid, block, 0, s, a);
+    dim3 grid((a.w + kFtW - 1) / kFtW, (a.h + kFtH - 1) / kFtH, a.n_slots > 0 ? a.n_slots : 1);
+    hipLaunchKernelGGL(fast_tile_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256) void panorama_normalize_kernel(const PanoNormA
 }
 
 // ---- 2x2 box half-sampler ---------------------------------------------------------------------
+typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
 __device__ __forceinline__ uint32_t half_px(int a, int b, int c, int d, int mode)
 {
     if (mode == DR3HIP_HALF_SSE2) {                       // _mm_avg_epu8 then _mm_avg_epu16
@@ -1011,38 +1012,53 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
     const uint8_t* __restrict__ src = a.src + (long long)blockIdx.z * a.sstep;      // grid z = frame slot
     uint8_t* __restrict__ dst = a.dst + (long long)blockIdx.z * a.dstep;
     uint32_t o[4] = {0, 0, 0, 0};
+    // 4 output pixels of a lane = 8 source bytes of two rows: one 8-byte load per row at whatever alignment the plane has (the
+    // half-sampled levels are continuous, their pitch is the odd width they happen to have)
+    auto quad = [&](const uint8_t* r0, const uint8_t* r1, int mode) {
+        const u32x2_unaligned t = *reinterpret_cast<const u32x2_unaligned*>(r0), b = *reinterpret_cast<const u32x2_unaligned*>(r1);
+        const uint32_t tw[2] = {t.x, t.y}, bw[2] = {b.x, b.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t tt = tw[k >> 1] >> (16 * (k & 1)), bb = bw[k >> 1] >> (16 * (k & 1));
+            o[k] = half_px(tt & 0xff, (tt >> 8) & 0xff, bb & 0xff, (bb >> 8) & 0xff, mode);
+        }
+    };
     if (a.mode == DR3HIP_HALF_REF_SCALAR) {
         // reference pointer walk: flat offset of output (Y, X) is Y*(2*ow + stride) + 2*X, where stride is the
         // step of the cv::Mat the reference holds (a.lstride); the bytes may sit in a wider-pitched plane here
         const int ls = a.lstride;
         const long long total = (long long)ls * a.h;
-        // element i of the continuous walk = (row i / ls, column i % ls) of the pitched plane; one division per output
-        // pixel: i + 1 and i + ls follow from (row, column) by a carry
-        auto at = [&](long long i, long long r, int c) -> int { return i < total ? src[r * a.sstride + c] : 0; };
+        // element i of the continuous walk = (row i / ls, column i % ls) of the pitched plane; i + 1 and i + ls follow from
+        // (row, column) by a carry
+        auto split = [&](long long t, long long& r, int& c) {
+            if (total < (1LL << 31)) { const uint32_t q = (uint32_t)t / (uint32_t)ls; r = q; c = (int)((uint32_t)t - q * (uint32_t)ls); }
+            else { r = t / ls; c = (int)(t - r * ls); }
+        };
+        const long long t0 = (long long)Y * (2LL * a.ow + ls) + 2LL * X;
+        long long r; int c;
+        split(t0, r, c);
+        if (X + 3 < a.ow && c + 8 <= ls && t0 + ls + 8 <= total) {
+            // the lane's 8 bytes of the walk and the 8 bytes one stride further exist and stay inside their rows: one division per lane
+            const uint8_t* r0 = src + r * a.sstride + c;
+            quad(r0, r0 + a.sstride, DR3HIP_HALF_TRUNC);
+        } else {
+            auto at = [&](long long i, long long rr, int cc) -> int { return i < total ? src[rr * a.sstride + cc] : 0; };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (X + k < a.ow) {
-                const long long t = (long long)Y * (2LL * a.ow + ls) + 2LL * (X + k);
-                long long r; int c;
-                if (total < (1LL << 31)) { const uint32_t q = (uint32_t)t / (uint32_t)ls; r = q; c = (int)((uint32_t)t - q * (uint32_t)ls); }
-                else { r = t / ls; c = (int)(t - r * ls); }
-                const bool wrap = c + 1 == ls;                                  // t + 1 starts the next row
-                const long long r1 = wrap ? r + 1 : r; const int c1 = wrap ? 0 : c + 1;
-                o[k] = half_px(at(t, r, c), at(t + 1, r1, c1), at(t + ls, r + 1, c), at(t + ls + 1, r1 + 1, c1), DR3HIP_HALF_TRUNC);
+            for (int k = 0; k < 4; ++k) {
+                if (X + k < a.ow) {
+                    const long long t = t0 + 2 * k;
+                    split(t, r, c);
+                    const bool wrap = c + 1 == ls;                                  // t + 1 starts the next row
+                    const long long r1 = wrap ? r + 1 : r; const int c1 = wrap ? 0 : c + 1;
+                    o[k] = half_px(at(t, r, c), at(t + 1, r1, c1), at(t + ls, r + 1, c), at(t + ls + 1, r1 + 1, c1), DR3HIP_HALF_TRUNC);
+                }
             }
         }
     } else {
         const uint8_t* r0 = src + (long long)(2 * Y) * a.sstride + 2 * X;
         const uint8_t* r1 = r0 + a.sstride;
-        const bool fast = (X + 3 < a.ow) && (((reinterpret_cast<uintptr_t>(src) | (uintptr_t)a.sstride) & 7) == 0);
-        if (fast) {
-            const uint2 t = *reinterpret_cast<const uint2*>(r0), b = *reinterpret_cast<const uint2*>(r1);
-            const uint32_t tw[2] = {t.x, t.y}, bw[2] = {b.x, b.y};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t tt = tw[k >> 1] >> (16 * (k & 1)), bb = bw[k >> 1] >> (16 * (k & 1));
-                o[k] = half_px(tt & 0xff, (tt >> 8) & 0xff, bb & 0xff, (bb >> 8) & 0xff, a.mode);
-            }
+        if (X + 3 < a.ow) {
+            quad(r0, r1, a.mode);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1050,8 +1066,9 @@ __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
         }
     }
     uint8_t* drow = dst + (long long)Y * a.dstride;
-    if (X + 3 < a.ow && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)a.dstride) & 3) == 0) {
-        *reinterpret_cast<uint32_t*>(drow + X) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    if (X + 3 < a.ow) {                                   // one dword store at whatever alignment the row has
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        *reinterpret_cast<u32_unaligned*>(drow + X) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (X + k < a.ow) drow[X + k] = (uint8_t)o[k];
