@@ -3,7 +3,7 @@
 // utils::shi_tomasi_score src/utils.cpp:282-321) for gfx950.  SURVEY 8f.2: this is what produces the
 // points the LK tracker consumes.  The `fast` library the reference links (CMakeLists.txt:17) is not
 // vendored; its published algorithm is restated here ("FAST"), parity unpinned.
-//   fast_tile_kernel    : one workgroup per 64 x 32 tile of a level, all phases out of LDS (see the kernel).  The library finds
+//   fast_tile_kernel    : one workgroup per 64 x 40 tile of a level, all phases out of LDS (see the kernel).  The library finds
 //                         the score by bisection over the corner test; the fixed point of that search has a closed form -- the
 //                         largest b for which 10 contiguous ring pixels are all > p + b (or all < p - b) is
 //                         max over the 16 arcs of min over the arc of (ring - p) (resp. p - ring), minus 1 --
@@ -82,9 +82,12 @@ __device__ __forceinline__ float shi_tomasi_from_sums(int sxx, int syy, int sxy)
 //  4. Shi-Tomasi score of the 8 x 8 box out of the image tile, then a 64-bit atomicMax per grid cell on (score bits, ~raster
 //     order): the reference keeps the first corner of the best score in level-major raster order.
 // No score map is written or read back on the detector's path, and the image is read once.
-constexpr int kFtW = 64, kFtH = 32;                        // pixels a workgroup decides
-constexpr int kFiPitch = 80, kFiRows = kFtH + 10;          // image tile: columns x0 - 8 .. x0 + 71, rows y0 - 5 .. y0 + kFtH + 4
-constexpr int kFsPitch = 72, kFsRows = kFtH + 2;           // score tile: columns x0 - 4 .. x0 + 67, rows y0 - 1 .. y0 + kFtH
+// Tile height kFtH: 40 (42 x 18 groups of 4 pixels = three full rounds of 256 lanes) or 32 (the same three rounds, a fifth of the lanes
+// idle in the last one): the launcher takes 40 where that means fewer tile rows, 32 otherwise (a 94-row level is three tile rows either way,
+// and three rows of 32 share the work more evenly than 40 + 40 + 14)
+constexpr int kFtW = 64;                                   // pixels a workgroup decides: kFtW x kFtH
+constexpr int kFiPitch = 80;                               // image tile: columns x0 - 8 .. x0 + 71, rows y0 - 5 .. y0 + kFtH + 4
+constexpr int kFsPitch = 72;                               // score tile: columns x0 - 4 .. x0 + 67, rows y0 - 1 .. y0 + kFtH
 constexpr int kFsGroups = kFsPitch / 4;                    // 4-pixel groups of a score row
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
@@ -119,8 +122,11 @@ __device__ __forceinline__ u16x2 second_extremes_beyond(u16x2 a, u16x2 b, u16x2 
     return __builtin_elementwise_sub_sat(s2l, hi) | __builtin_elementwise_sub_sat(lo, s2s);
 }
 
+template <int kFtH>
 __global__ __launch_bounds__(256) void fast_tile_kernel(const FastArgs a)
 {
+    constexpr int kFiRows = kFtH + 10, kFsRows = kFtH + 2;
+    static_assert(kFiRows * (kFiPitch / 16) <= 256 && (kFsRows * kFsPitch) % 16 == 0, "one staging round; the score tile is cleared 16 bytes at a time");
     __shared__ uint32_t s_img[kFiRows * kFiPitch / 4];
     __shared__ uint32_t s_score[kFsRows * kFsPitch / 4];
     __shared__ uint16_t s_cand[kFsRows * kFsPitch];          // (score row << 7) | score column
@@ -470,8 +476,10 @@ hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s)
 hipError_t launch_fast_level(const FastArgs& a, hipStream_t s)
 {
     if (a.w <= 0 || a.h <= 0) return hipSuccess;
-    dim3 grid((a.w + kFtW - 1) / kFtW, (a.h + kFtH - 1) / kFtH, a.n_slots > 0 ? a.n_slots : 1);
-    hipLaunchKernelGGL(fast_tile_kernel, grid, dim3(256), 0, s, a);
+    const int th = (a.h + 39) / 40 < (a.h + 31) / 32 ? 40 : 32;
+    dim3 grid((a.w + kFtW - 1) / kFtW, (a.h + th - 1) / th, a.n_slots > 0 ? a.n_slots : 1);
+    if (th == 40) hipLaunchKernelGGL(fast_tile_kernel<40>, grid, dim3(256), 0, s, a);
+    else          hipLaunchKernelGGL(fast_tile_kernel<32>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
