@@ -33,8 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PRE_ROLL_STEPS = 32          # untimed steady-state pre-roll before the W warm-up steps (about 40 ms of device time: the
-                             # tracker's launches keep getting faster for that long, 1.25 -> 1.00 ms in profiles/r02_v1's kernel trace)
+PRE_ROLL_STEPS = int(os.environ.get("DR3_BENCH_PRE_ROLL", "256"))
+                             # untimed steady-state pre-roll before the W warm-up steps (about 0.3 s of device time).  The part keeps
+                             # settling for longer than round 2's 32 steps allowed on some boxes: 20 timed steps right after them took
+                             # 1.19 ms each where 400 took 1.12 (round 3, same process); the metric is a stream's steady state
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (a measured copy rate is reported as hbm_copy_measured_GBps)
 
 KITTI_W, KITTI_H = 1241, 376
@@ -160,17 +162,25 @@ def launch_ranks(n, argv):
 def timed_region(dist, step_fn, sync_fn, steps, warmup):
     """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides.
     Returns the MAX elapsed seconds over ranks."""
+    import gc
     for _ in range(warmup):
         step_fn()
     sync_fn()
-    dist.barrier()
-    sync_fn()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
-    sync_fn()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # the interpreter's cyclic collector stays out of the timed loop (a full collection of this process takes 35 - 45 ms, twice the
+    # 20 default steps; it was caught in the host-buffer leg, one call in 200).  It is switched off, not run, here: 40 ms of idle
+    # device right before the loop cost the first 20 launches 11 % (tools/step_decay.sh) -- the caller collects before its warm-up
+    gc.disable()
+    try:
+        dist.barrier()
+        sync_fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync_fn()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     return dist.max_over_ranks(elapsed)
 
 
@@ -429,6 +439,8 @@ def main(argv=None):
     # ---- timed region --------------------------------------------------------------------------
     # Pre-roll, independent of --warmup: code objects load at first launch and the part needs some tens of milliseconds
     # of load to settle its clocks (5 timed steps right after 2 warm-up steps measured 2.18 ms per step, 20 steps 2.06).
+    import gc
+    gc.collect()                                                 # before the pre-roll, so that no collection falls into the timed steps
     for _ in range(PRE_ROLL_STEPS):
         step()
     sync()
@@ -493,10 +505,15 @@ def main(argv=None):
         n_host = 200
         ctx.calcOpticalFlowPyrLK(frames[0], frames[1], pts, None, params)                    # warm-up (staging buffers)
         t_call = np.empty(n_host)
-        for i in range(n_host):
-            t0 = time.perf_counter()
-            ctx.calcOpticalFlowPyrLK(frames[i % B], frames[i % B + 1], pts, None, params)
-            t_call[i] = time.perf_counter() - t0
+        import gc
+        gc.collect(); gc.disable()                               # the interpreter's collector is not part of the C ABI's time
+        try:
+            for i in range(n_host):
+                t0 = time.perf_counter()
+                ctx.calcOpticalFlowPyrLK(frames[i % B], frames[i % B + 1], pts, None, params)
+                t_call[i] = time.perf_counter() - t0
+        finally:
+            gc.enable()
         # the rate is the mean over all calls; the median and the slowest call stand beside it because a single host-side stall of
         # some tens of milliseconds (seen on some boxes, in one call of a run) is otherwise indistinguishable from a slow path
         host_api = {"keypoints_per_sec": n_host * N_PTS / t_call.sum(), "ms_per_pair": t_call.mean() * 1e3,
@@ -756,11 +773,17 @@ def post_lk_leg(dist, ctx, dr3, d_prev, d_next, d_st, pts, n_pts, sync):
 
     for name, fn in (("check_fundamental_ms", vote), ("normalize_two_sets_ms", norm)):
         fn(); sync()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            fn()
-        sync()
-        out[name] = (time.perf_counter() - t0) / 50 * 1e3
+        # host clock around batches of 10 calls, the median batch: one host-side stall of some tens of milliseconds (seen on some boxes,
+        # see host_api_pcie_inclusive) inside a single window of 50 calls would otherwise read as a ten times slower kernel
+        per_batch = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            sync()
+            per_batch.append((time.perf_counter() - t0) / 10 * 1e3)
+        out[name] = float(np.median(per_batch))
+        out[name.replace("_ms", "_slowest_batch_ms")] = float(max(per_batch))
     if dist.rank == 0:
         from oracle import oracle as O
         p1 = d_prev.download((n_pts, 2), np.float32); p2 = d_next.download((n_pts, 2), np.float32); st = d_st.download((n_pts,), np.uint8)
