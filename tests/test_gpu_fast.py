@@ -29,6 +29,26 @@ def test_fast10_score_map_bit_exact(dr3, O, ctx, synth, w, h):
     assert np.array_equal(ctx.fast_score_map(noise, 35), O.fast10_score_map(noise, 35))
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (5, 9), (7, 7), (8, 40), (63, 31), (64, 32), (65, 33), (66, 40), (67, 41), (129, 80), (131, 81),
+                                 (192, 94), (200, 120), (61, 200)])
+def test_tile_kernel_at_the_edges_of_its_tiles(dr3, O, ctx, w, h):
+    """the fused detector kernel decides 64 x 40 or 64 x 32 tiles (whichever gives fewer tile rows) out of LDS, with a border of 5 rows / 8
+    columns: sizes around every one of those numbers, images smaller than the ring, thresholds at both ends -- score map, and corners
+    through both entry points, on an image where most pixels are candidates (every list of the kernel fills up)"""
+    rng = np.random.default_rng(1000 * w + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[rng.random((h, w)) < 0.3] = 0
+    for thr in (1, 20, 254):
+        assert np.array_equal(ctx.fast_score_map(img, thr), O.fast10_score_map(img, thr)), thr
+    if w >= 8 and h >= 8:
+        for cell, thr in ((5, 10), (16, 30)):
+            o = O.fast_detect_grid([img], cell, thr, 0.0)
+            g = ctx.fast_detect(img, 1, cell, thr, 0.0)
+            m = o[3] >= 0
+            assert np.array_equal(g[3], o[3]), (cell, thr)
+            assert np.array_equal(g[0][m], o[0][m]) and np.array_equal(g[1][m], o[1][m]) and np.array_equal(g[2][m].view(np.uint32), o[2][m].view(np.uint32))
+
+
 @pytest.mark.parametrize("w,h,levels,cell", [(1241, 376, 3, 30), (640, 480, 3, 30), (1920, 1080, 5, 20), (203, 131, 2, 25)])
 def test_fast_detect_grid_matches_oracle(dr3, O, ctx, synth, w, h, levels, cell):
     img = _corner_rich(synth, w, h, 7 * w + h)
