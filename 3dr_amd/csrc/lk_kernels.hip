@@ -12,10 +12,11 @@
 //     windows of <= 128 items (the reference's 30x30)   PPW = 1   64 lanes, 2 items per lane
 // (windows up to 16 x 16 run as PPW = 8 since round 3: 8 lanes per point, a lane owns the columns hl and hl + 8, two lane-items.)
 // What bounds the kernel's per-level phase is the NUMBER of vector-memory instructions: the CU's texture path takes about 16 clocks per
-// wave-instruction whatever its width, plus a clock or so per extra cache line (tools/ubench/vmem_rate.hip).  The eight-point form
-// therefore stages the J region AND the template's image rows with 8-byte loads of two rows per instruction (12 + 8 instead of 24 + 32
-// instructions per level; the image bytes then come out of LDS), and with a compile-time window it issues the template's 32
-// derivative loads together with those staging loads, before the LDS writes: one memory round trip per level, 52 loads in flight.
+// wave-instruction whatever its width, plus a clock or so per extra cache line (tools/ubench/vmem_rate.hip).  Every form therefore
+// stages the J region AND the template's image rows with 8-byte loads, a group's lanes = (row of the round, 8-byte piece) -- the
+// eight-point form: 12 + 8 instead of 24 + 32 instructions per level; the image bytes then come out of LDS --, and with a compile-time
+// window it issues the template's derivative loads together with those staging loads, before the LDS writes: one memory round trip per
+// level (15 x 15: 52 loads in flight).
 // Column ownership makes the 16 lanes of a column group load ADJACENT addresses (a wave-instruction touches a handful of cache
 // lines; with a lane per window row it touched 64, and the L1's line rate bound the kernel), and lets tap r reuse the permuted
 // byte pair of row r + 1 as tap r + 1's row r: one v_perm_b32 per row instead of two per tap.
@@ -170,9 +171,9 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #define LKG_WAVES_P8 3       // eight points per wave: two 16-tap columns per lane
 #endif
 #ifndef LKG_WIDE
-#define LKG_WIDE 1           // eight points per wave: the J region and the template's image rows are staged with 8-byte loads, two rows per
-                             // instruction (1 = on).  The CU's texture path takes ~16 clocks per wave-instruction whatever its width
-                             // (tools/ubench/vmem_rate.hip), and the tracker's time is its vector-memory instructions times that
+#define LKG_WIDE 1           // the J region and the template's image rows are staged with 8-byte loads, several rows per instruction
+                             // (1 = on).  The CU's texture path takes ~16 clocks per wave-instruction whatever its width
+                             // (tools/ubench/vmem_rate.hip), and the tracker's per-level time is its vector-memory instructions times that
 #endif
 #ifndef LKG_PRE
 #define LKG_PRE 1
@@ -187,12 +188,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     constexpr int LANES = 64 / PPW;               // lanes per point
-    constexpr bool WIDE = PPW == 8 && LKG_WIDE;
+    constexpr bool WIDE = LKG_WIDE != 0;
     constexpr bool PRE = WIDE && WIN != 0 && LKG_PRE;          // the template's derivative loads are issued with the staging loads
-    constexpr int IROWS = WIN ? (WIN + 2) / 2 * 2 : 18, IPITCH = 7;   // WIDE: staged template image rows per point (even), dwords per row (6 used)
     constexpr int NT = PPW >= 4 ? 16 : 8;         // taps (consecutive window rows of one column) per lane-item
     constexpr int COLS = PPW >= 4 ? 8 : 16;       // dword columns of the staging grid (>= the region's width)
     constexpr int SR = LANES / COLS;              // rows a group stages per round
+    // WIDE staging: a row is fetched as PCS pieces of 8 bytes (4 COLS bytes: the J region's row and the template's image row both fit),
+    // a round of the group's lanes covers RPR rows
+    constexpr int PCS = COLS / 2, RPR = LANES / PCS, IPITCH = COLS + 1;
+    // staged template image rows per point: the rows its lane-items read (a whole column + 1, or 8-row items up to 8 nblk + 1), in whole rounds
+    constexpr int IROWS = ((WIN ? (PPW >= 4 ? WIN + 1 : 8 * ((WIN + 7) / 8) + 1) : (PPW >= 4 ? 17 : 33)) + RPR - 1) / RPR * RPR;
     static_assert((PPW != 4 || NI == 1) && (PPW != 8 || NI == 2), "a quarter wave holds one window column per lane, an eighth two");
 
     const int lane = threadIdx.x, hl = lane & (LANES - 1), grp = lane / LANES;
@@ -209,11 +214,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
 
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
     const int nblk = PPW >= 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
-    const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = WIDE ? 9 : rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd; WIDE: 4 pieces of 2 dwords + 1)
+    const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = WIDE ? COLS + 1 : rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd; WIDE: PCS pieces of 2 dwords + 1)
     // LDS rows per group: staging runs in rounds of SR rows.  Every form but the compile-time column forms (WIN with PPW >= 4, whose
     // tap_live() stops at the window) also reads (and masks) the rows of the taps below the window: a lane-item of NT rows starting at
     // ity, up to 8 rows into the region, reaches row 8 + ity + NT <= win_h + 15 of the slice
-    const int rhs = (((WIN && PPW >= 4) ? rh : PPW >= 4 ? 25 : win_h + 16) + SR - 1) / SR * SR;
+    constexpr int SRW = WIDE ? RPR : SR;          // rows per staging round
+    const int rhs = (((WIN && PPW >= 4) ? rh : PPW >= 4 ? 25 : win_h + 16) + SRW - 1) / SRW * SRW;
     static_assert(!(WIN && PPW < 4) || 8 + 8 * ((WIN + 7) / 8 - 1) + 8 <= WIN + 15, "the slice of a group holds every row its lane-items read");
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -258,17 +264,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     // WIDE: the J region rows [ry, ry + rh) x bytes [rx, rx + 32) of the current level into the group's slice: lane = (row of a pair, 8-byte piece)
     gbase_t Jb = nullptr; int Jpitch = 0, Jpad_x = 0, Jpad_y = 0;            // set per level
     auto stage_J_wide = [&](int rx, int ry) {
-        const int rr = hl >> 2, pc = hl & 3;
+        const int rr = hl / PCS, pc = hl & (PCS - 1);
         uint32_t off = __umul24((unsigned)(ry + Jpad_y + rr), (unsigned)Jpitch) + (unsigned)(rx + Jpad_x + 8 * pc);
         uint32_t* st = lds + rr * lpd + 2 * pc;
         if (WIN) {
-            u32x2 v[(WIN + 10) / 2];
+            constexpr int JR = (WIN + 9 + RPR - 1) / RPR;                    // rows up to JR RPR - 1 < rhs exist in memory: slack rows
+            u32x2 v[JR];
 #pragma unroll
-            for (int k = 0; k < (WIN + 10) / 2; ++k) { v[k] = ldg<u32x2>(Jb, off); off += 2u * (unsigned)Jpitch; }      // rows up to rh (even) exist: slack rows
+            for (int k = 0; k < JR; ++k) { v[k] = ldg<u32x2>(Jb, off); off += (unsigned)RPR * (unsigned)Jpitch; }
 #pragma unroll
-            for (int k = 0; k < (WIN + 10) / 2; ++k) { st[2 * k * lpd] = v[k].x; st[2 * k * lpd + 1] = v[k].y; }
+            for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = v[k].x; st[RPR * k * lpd + 1] = v[k].y; }
         } else {
-            for (int r = rr; r < rh; r += 2) { const u32x2 v = ldg<u32x2>(Jb, off); st[(r - rr) * lpd] = v.x; st[(r - rr) * lpd + 1] = v.y; off += 2u * (unsigned)Jpitch; }
+            for (int r = rr; r < rh; r += RPR) { const u32x2 v = ldg<u32x2>(Jb, off); st[(r - rr) * lpd] = v.x; st[(r - rr) * lpd + 1] = v.y; off += (unsigned)RPR * (unsigned)Jpitch; }
         }
     };
 
@@ -321,28 +328,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
             rx0 = (cxs - RM) & ~3;
             ry0 = cys - RM;
             if constexpr (WIDE) {
-                // the template's image rows first (they depend on the previous point only): bytes (xp0 & ~3) .. + 24 of IROWS rows, lanes 0-5 of a
-                // point = (row of the pair, 8-byte piece); lanes 6, 7 repeat lane 5.  Then the J region, 4 pieces x 2 rows per instruction.
+                // the template's image rows first (they depend on the previous point only): bytes (xp0 & ~3) .. + 4 COLS of IROWS rows, a lane =
+                // (row of the round, 8-byte piece).  Then the J region the same way.
                 const int xp0 = (act ? ipx : 0) + pad_x, yp0 = (act ? ipy : 0) + pad_y;
-                const int h6 = min(hl, 5), rrI = h6 >= 3 ? 1 : 0, pcI = h6 - 3 * rrI;
-                uint32_t offI = __umul24((unsigned)(yp0 + rrI), (unsigned)pitch) + ((unsigned)xp0 & ~3u) + 8u * (unsigned)pcI;
-                uint32_t* stI = ldsI + rrI * IPITCH + 2 * pcI;
-                u32x2 vi[IROWS / 2];
+                const int rr = hl / PCS, pc = hl & (PCS - 1);
+                uint32_t offI = __umul24((unsigned)(yp0 + rr), (unsigned)pitch) + ((unsigned)xp0 & ~3u) + 8u * (unsigned)pc;
+                uint32_t* stI = ldsI + rr * IPITCH + 2 * pc;
+                u32x2 vi[IROWS / RPR];
 #pragma unroll
-                for (int k = 0; k < IROWS / 2; ++k) { vi[k] = ldg<u32x2>(Ibase, offI); offI += 2u * (unsigned)pitch; }
+                for (int k = 0; k < IROWS / RPR; ++k) { vi[k] = ldg<u32x2>(Ibase, offI); offI += (unsigned)RPR * (unsigned)pitch; }
                 if constexpr (PRE) {
                     // compile-time window: the J region's loads, then the template's derivative loads (they wait for nothing either), and only
                     // then the LDS writes of the staged rows -- loads return in order, so waiting for the staged rows leaves the derivative
                     // rows in flight: ONE memory round trip per level instead of two
-                    const int rr = hl >> 2, pc = hl & 3;
+                    constexpr int JR = (WIN + 9 + RPR - 1) / RPR;
                     uint32_t off = __umul24((unsigned)(ry0 + pad_y + rr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 8 * pc);
                     uint32_t* st = lds + rr * lpd + 2 * pc;
-                    u32x2 vj[(WIN + 10) / 2];
+                    u32x2 vj[JR];
 #pragma unroll
-                    for (int k = 0; k < (WIN + 10) / 2; ++k) { vj[k] = ldg<u32x2>(Jbase, off); off += 2u * (unsigned)pitch; }
+                    for (int k = 0; k < JR; ++k) { vj[k] = ldg<u32x2>(Jbase, off); off += (unsigned)RPR * (unsigned)pitch; }
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
-                        const uint32_t offD = __umul24((unsigned)yp0, (unsigned)dpitch) + 4u * (unsigned)(xp0 + itx[i]);
+                        const uint32_t offD = __umul24((unsigned)(yp0 + ity[i]), (unsigned)dpitch) + 4u * (unsigned)(xp0 + itx[i]);
                         gbase_t rowD = Dbase;
 #pragma unroll
                         for (int r = 0; r <= NT; ++r)
@@ -350,12 +357,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                     }
                     __builtin_amdgcn_sched_barrier(0);           // the scheduler would sink the loads to their uses behind the LDS writes
 #pragma unroll
-                    for (int k = 0; k < (WIN + 10) / 2; ++k) { st[2 * k * lpd] = vj[k].x; st[2 * k * lpd + 1] = vj[k].y; }
+                    for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = vj[k].x; st[RPR * k * lpd + 1] = vj[k].y; }
                 } else {
                     stage_J_wide(rx0, ry0);
                 }
 #pragma unroll
-                for (int k = 0; k < IROWS / 2; ++k) { stI[2 * k * IPITCH] = vi[k].x; stI[2 * k * IPITCH + 1] = vi[k].y; }
+                for (int k = 0; k < IROWS / RPR; ++k) { stI[RPR * k * IPITCH] = vi[k].x; stI[RPR * k * IPITCH + 1] = vi[k].y; }
             } else {
             uint32_t off = __umul24((unsigned)(ry0 + pad_y + sr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 4 * sc);
             const uint32_t step = (uint32_t)SR * (unsigned)pitch;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                 int gx[2], gy[2];
                 gbase_t rowI = Ibase, rowD = Dbase;          // wave-uniform row bases, advanced on the scalar unit
                 // WIDE: the image bytes come out of the staged rows: byte (first column & 3) + column of the row
-                const uint32_t* pI = ldsI + (((((uint32_t)xp - (uint32_t)itx[i]) & 3u) + (uint32_t)itx[i]) >> 2);
+                const uint32_t* pI = ldsI + ity[i] * IPITCH + (((((uint32_t)xp - (uint32_t)itx[i]) & 3u) + (uint32_t)itx[i]) >> 2);
 #pragma unroll
                 for (int r = 0; r <= NT; ++r) {
                     uint32_t P = 0, X = 0, Y = 0;
@@ -660,13 +667,16 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     if (a.win_w < 3 || a.win_h < 3 || a.win_w > 32 || a.win_h > 32) return hipErrorInvalidValue;
     int ppw, ni;
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
-    const bool wide = ppw == 8 && LKG_WIDE;
-    const int sr = 64 / ppw / (ppw >= 4 ? 8 : 16), lpd = wide ? 9 : ((a.win_w + 15) / 4) | 1;
+    const bool wide = LKG_WIDE != 0;
+    const int cols = ppw >= 4 ? 8 : 16, lanes = 64 / ppw, rpr = lanes / (cols / 2);
+    const int sr = wide ? rpr : lanes / cols, lpd = wide ? cols + 1 : ((a.win_w + 15) / 4) | 1;
     const bool fixed = a.win_w == a.win_h && (a.win_w == 15 || a.win_w == 21 || a.win_w == 30);
     const int rhs = (((fixed && ppw >= 4) ? a.win_h + 9 : ppw >= 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;     // as in the kernel
     dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
-    // the groups' J regions; eight points per wave: behind them the template's staged image rows (IROWS x IPITCH dwords per point)
-    const size_t shmem = ((size_t)ppw * rhs * lpd + (wide ? (size_t)ppw * ((fixed && a.win_w == 15) ? 16 : 18) * 7 : 0)) * sizeof(uint32_t);
+    // the groups' J regions; wide staging: behind them the template's staged image rows (IROWS x IPITCH dwords per point, as in the kernel)
+    const int irows_need = fixed ? (ppw >= 4 ? a.win_w + 1 : 8 * ((a.win_w + 7) / 8) + 1) : (ppw >= 4 ? 17 : 33);
+    const int irows = (irows_need + rpr - 1) / rpr * rpr;
+    const size_t shmem = ((size_t)ppw * rhs * lpd + (wide ? (size_t)ppw * irows * (cols + 1) : 0)) * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
     if (ppw == 8) {
         if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 8, 2>), grid, block, shmem, s, a);
