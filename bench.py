@@ -890,6 +890,14 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
         out[name] = {"kernel": kernel, "levels": b.levels, "pairs_per_launch": NP, "points_per_pair": n, "kernel_ms": k_ms,
                      "keypoints_per_sec_kernel_only": NP * n / (k_ms * 1e-3), "tracked_fraction": float(d_st.download((NP, n), np.uint8).mean()),
                      "verified_vs_oracle": ok}
+        if have_gpu:                                       # iteration-levels per point and per lock-step group (what tools/lk_valu_mix.py weights by)
+            d_it = ctx.alloc(NP * n * b.levels * 4)
+            d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params, d_iters=d_it); sync()
+            it = d_it.download((NP, n, b.levels), np.int32).sum(2)
+            ppw = int(kernel.split(",")[1])
+            out[name]["mean_iteration_levels_per_point"] = float(it.mean())
+            out[name]["mean_iteration_levels_of_slowest_in_group"] = float(it[:, :n // ppw * ppw].reshape(NP, -1, ppw).max(2).mean())
+            d_it.free()
         for d in (d_prev, d_next, d_st, d_err):
             d.free()
         b.close()
