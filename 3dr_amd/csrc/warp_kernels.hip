@@ -787,29 +787,33 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
 //   cylindrical xhat = (float)sin th,            yhat = height,        zhat = (float)cos th
 //   xhat /= zhat; yhat /= zhat;  u = xhat * f + 0.5 w;  v = yhat * f + 0.5 h      (all f32, no FMA)
 // which replaces six full-image f32 passes and the 8 B/px map read by 16 (w + h) bytes of tables.
-template <int MAPS>
-__device__ __forceinline__ Tap map_tap(const RemapArgs& a, const float* __restrict__ mx, const float* __restrict__ my, int x, int y)
+// cvRound(map * INTER_TAB_SIZE): f32 multiply, round half to even; NaN, infinities and out-of-range products give
+// x86's "integer indefinite" 0x80000000 there (cvtss2si), not the saturated value of v_cvt_i32_f32
+__device__ __forceinline__ Tap map_tap_uv(float u, float v)
 {
-    float u, v;
-    if (MAPS == 0) {
-        u = mx[x]; v = my[x];
-    } else {
-        float xhat, yhat, zhat;
-        if (MAPS == 1) {
-            const double cy = a.ty1[y];
-            xhat = (float)(a.tx0[x] * cy); yhat = (float)a.ty0[y]; zhat = (float)(a.tx1[x] * cy);
-        } else {
-            xhat = (float)a.tx0[x]; yhat = (float)a.ty0[y]; zhat = (float)a.tx1[x];
-        }
-        xhat /= zhat; yhat /= zhat;
-        u = xhat * a.f + a.half_w; v = yhat * a.f + a.half_h;
-    }
-    // cvRound(map * INTER_TAB_SIZE): f32 multiply, round half to even; NaN, infinities and out-of-range products give
-    // x86's "integer indefinite" 0x80000000 there (cvtss2si), not the saturated value of v_cvt_i32_f32
     const float us = u * 32.f, vs = v * 32.f;
     const int X = (us >= -2147483648.f && us < 2147483648.f) ? __float2int_rn(us) : (int)0x80000000;
     const int Y = (vs >= -2147483648.f && vs < 2147483648.f) ? __float2int_rn(vs) : (int)0x80000000;
     return tap_from_fixed(X, Y);
+}
+
+// (u, v) of one pixel from its column table entries (c0 = tx0[x], c1 = tx1[x]) and row table entries (r0 = ty0[y], r1 = ty1[y]), in
+// the reference's exact order (see above)
+template <int MAPS>
+__device__ __forceinline__ Tap map_tap_tables(const RemapArgs& a, double c0, double c1, double r0, double r1)
+{
+    float xhat, yhat, zhat;
+    if (MAPS == 1) { xhat = (float)(c0 * r1); yhat = (float)r0; zhat = (float)(c1 * r1); }
+    else           { xhat = (float)c0;        yhat = (float)r0; zhat = (float)c1; }
+    xhat /= zhat; yhat /= zhat;
+    return map_tap_uv(xhat * a.f + a.half_w, yhat * a.f + a.half_h);
+}
+
+template <int MAPS>
+__device__ __forceinline__ Tap map_tap(const RemapArgs& a, const float* __restrict__ mx, const float* __restrict__ my, int x, int y)
+{
+    if (MAPS == 0) return map_tap_uv(mx[x], my[x]);
+    return map_tap_tables<MAPS>(a, a.tx0[x], a.tx1[x], a.ty0[y], MAPS == 1 ? a.ty1[y] : 0.0);
 }
 
 template <int TYPE, int MAPS>
@@ -823,10 +827,36 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
     const float* mx = MAPS ? nullptr : reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapx) + (long long)y * a.map_stride);
     const float* my = MAPS ? nullptr : reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(a.mapy) + (long long)y * a.map_stride);
     Tap t[P::PXT];
+    bool have_taps = false;
+    if constexpr (MAPS == 0 && P::PXT == 4) {
+        // the map values of the lane's four pixels as one 16-byte load per plane (a vector-memory instruction costs the texture path
+        // the same ~16 clocks whatever its width, tools/ubench/vmem_rate.hip) where the rows allow it
+        if (x + 3 < a.dw && ((reinterpret_cast<uintptr_t>(mx) | reinterpret_cast<uintptr_t>(my)) & 15) == 0) {
+            const float4 ux = *reinterpret_cast<const float4*>(mx + x), vy = *reinterpret_cast<const float4*>(my + x);
+            const float u4[4] = {ux.x, ux.y, ux.z, ux.w}, v4[4] = {vy.x, vy.y, vy.z, vy.w};
 #pragma unroll
-    for (int i = 0; i < P::PXT; ++i) {
-        t[i] = tap_from_fixed(0, 0);
-        if (x + i < a.dw) t[i] = map_tap<MAPS>(a, mx, my, x + i, y);
+            for (int i = 0; i < 4; ++i) t[i] = map_tap_uv(u4[i], v4[i]);
+            have_taps = true;
+        }
+    }
+    if constexpr (MAPS != 0 && P::PXT == 4) {
+        // in-kernel maps: the column tables of the lane's four pixels as two 16-byte loads each instead of four 8-byte ones
+        if (x + 3 < a.dw && ((reinterpret_cast<uintptr_t>(a.tx0) | reinterpret_cast<uintptr_t>(a.tx1)) & 15) == 0) {
+            const double2 c0a = *reinterpret_cast<const double2*>(a.tx0 + x), c0b = *reinterpret_cast<const double2*>(a.tx0 + x + 2);
+            const double2 c1a = *reinterpret_cast<const double2*>(a.tx1 + x), c1b = *reinterpret_cast<const double2*>(a.tx1 + x + 2);
+            const double t0[4] = {c0a.x, c0a.y, c0b.x, c0b.y}, t1[4] = {c1a.x, c1a.y, c1b.x, c1b.y};
+            const double r0 = a.ty0[y], r1 = MAPS == 1 ? a.ty1[y] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = map_tap_tables<MAPS>(a, t0[i], t1[i], r0, r1);
+            have_taps = true;
+        }
+    }
+    if (!have_taps) {
+#pragma unroll
+        for (int i = 0; i < P::PXT; ++i) {
+            t[i] = tap_from_fixed(0, 0);
+            if (x + i < a.dw) t[i] = map_tap<MAPS>(a, mx, my, x + i, y);
+        }
     }
     if (P::PXT == 4) quad_8u<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dw, a.dstride, x, y, t);
     else             single_px<TYPE>((gcu8)a.src, a.sw, a.sh, a.sstride, (gu8)a.dst, a.dstride, x, y, t[0]);
