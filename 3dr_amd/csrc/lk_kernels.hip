@@ -335,8 +335,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                 uint32_t offI = __umul24((unsigned)(yp0 + rr), (unsigned)pitch) + ((unsigned)xp0 & ~3u) + 8u * (unsigned)pc;
                 uint32_t* stI = ldsI + rr * IPITCH + 2 * pc;
                 u32x2 vi[IROWS / RPR];
+                // run-time windows: IROWS is the count for the largest window of the shape; rows past those the lane-items of THIS window
+                // read (the plane's slack below its bottom border covers exactly those) are replaced by the last such row
+                const int irows_need = PPW >= 4 ? NT + 1 : 8 * nblk + 1;
 #pragma unroll
-                for (int k = 0; k < IROWS / RPR; ++k) { vi[k] = ldg<u32x2>(Ibase, offI); offI += (unsigned)RPR * (unsigned)pitch; }
+                for (int k = 0; k < IROWS / RPR; ++k) {
+                    if (WIN) { vi[k] = ldg<u32x2>(Ibase, offI); offI += (unsigned)RPR * (unsigned)pitch; }
+                    else vi[k] = ldg<u32x2>(Ibase, __umul24((unsigned)(yp0 + min(RPR * k + rr, irows_need - 1)), (unsigned)pitch) + ((unsigned)xp0 & ~3u) + 8u * (unsigned)pc);
+                }
                 if constexpr (PRE) {
                     // compile-time window: the J region's loads, then the template's derivative loads (they wait for nothing either), and only
                     // then the LDS writes of the staged rows -- loads return in order, so waiting for the staged rows leaves the derivative
