@@ -103,3 +103,16 @@ def test_committed_profiles_were_made_from_the_kernel_sources_in_the_tree():
         assert json.load(open(os.path.join(prof, f)))["source_hash"] == want, f
     assert d["lk_kernel"]["valu_issue"] is not None and d["roofline"]["traffic"] is not None
     assert os.path.dirname(os.path.join(ROOT, d["roofline"]["traffic_source"])) == prof
+
+
+def test_strip_kernel_launch_shape_matches_the_recorded_traffic_shapes():
+    """bench.strip_grid_threads restates launch_warp's grid of warp_tile_8uc3_kernel (64 x 64 tiles, padded to 8 x run blocks, 256 threads):
+    the per-shape PMC traffic is looked up by it, so it must name the shapes the committed summary recorded"""
+    import bench
+    assert bench.strip_grid_threads(4000, 3000, 8) == 6094848          # 63 x 47 tiles -> 2976 blocks (runs of 4 per XCD) x 8 jobs
+    assert bench.strip_grid_threads(1241, 376, 256) == 7864320         # 20 x 6 tiles, raster order, x 256 jobs
+    prof, _ = bench.newest_profile("pmc_traffic_warp.json")
+    if prof:
+        strip = [v for k, v in prof.get("kernels", prof).items() if isinstance(v, dict) and "warp_tile_8uc3_kernel" in k]
+        if strip:
+            assert {"6094848", "7864320"} <= set(strip[0].get("shapes", {}).keys())
