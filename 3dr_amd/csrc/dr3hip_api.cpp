@@ -49,6 +49,7 @@ struct dr3hip_ctx {
         hipEvent_t copied[K] = {nullptr}, consumed[K] = {nullptr}; bool used[K] = {false};
         hipEvent_t computed = nullptr;    // marks the point of the compute stream a download waits for
         int next = 0;
+        bool ready = false;               // every stream and event above exists
     } xf;
 };
 
@@ -247,7 +248,7 @@ static void xfer_release(dr3hip_ctx* ctx)
     if (x.computed) (void)hipEventDestroy(x.computed);
     if (x.up) (void)hipStreamDestroy(x.up);
     if (x.down) (void)hipStreamDestroy(x.down);
-    x.computed = nullptr; x.up = x.down = nullptr; x.cap = 0;
+    x.computed = nullptr; x.up = x.down = nullptr; x.cap = 0; x.ready = false;
 }
 
 void dr3hip_destroy(dr3hip_ctx* ctx)
@@ -291,7 +292,16 @@ int dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream)
     else prof_drain(ctx);
     if (e != hipSuccess && ctx->stream == ctx->own_stream) return fail(ctx, DR3HIP_EHIP, "set_stream: draining the context's stream failed: %s", hipGetErrorString(e));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    if (e != hipSuccess) { ctx->pending.clear(); return fail(ctx, DR3HIP_EHIP, "set_stream: the previous stream could not be drained (%s); switched anyway", hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        // the events queued on the dead stream are never read: destroy the ones this context owns rather than dropping the handles
+        for (ProfEvent& pe : ctx->pending) {
+            if (pe.own0 && pe.e0) (void)hipEventDestroy(pe.e0);
+            if (pe.own1 && pe.e1) (void)hipEventDestroy(pe.e1);
+        }
+        ctx->pending.clear();
+        (void)hipGetLastError();
+        return fail(ctx, DR3HIP_EHIP, "set_stream: the previous stream could not be drained (%s); switched anyway", hipGetErrorString(e));
+    }
     return DR3HIP_OK;
 }
 
@@ -1098,14 +1108,22 @@ int dr3hip_batch_upload(dr3hip_batch* b, int first, int count, const uint8_t* fr
 static int xfer_init(dr3hip_ctx* ctx, size_t chunk_bytes)
 {
     dr3hip_ctx::Xfer& x = ctx->xf;
-    if (!x.up) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&x.up, hipStreamNonBlocking));
-        HIPCHK(ctx, hipStreamCreateWithFlags(&x.down, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&x.computed, hipEventDisableTiming));
-        for (int i = 0; i < dr3hip_ctx::Xfer::K; ++i) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&x.copied[i], hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&x.consumed[i], hipEventDisableTiming));
+    if (!x.ready) {
+        // every stream and event must exist before the transfer state counts as initialised: a half-built state is torn down again,
+        // so that the next call starts from nothing instead of using null handles
+        hipError_t e = hipStreamCreateWithFlags(&x.up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&x.down, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&x.computed, hipEventDisableTiming);
+        for (int i = 0; i < dr3hip_ctx::Xfer::K && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&x.copied[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&x.consumed[i], hipEventDisableTiming);
         }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            xfer_release(ctx);
+            return fail(ctx, DR3HIP_EHIP, "streaming transfers: %s", hipGetErrorString(e));
+        }
+        x.ready = true;
     }
     if (x.cap >= chunk_bytes) return DR3HIP_OK;
     HIPCHK(ctx, hipStreamSynchronize(x.up));

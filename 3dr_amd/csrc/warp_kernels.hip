@@ -1120,7 +1120,9 @@ hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max
             const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
             dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp), n_jobs, 1);
             int lds = (std::max(tile_lds, 1024) + 255) & ~255;               // a wave's slice; behind it the wave's tie list (256 B)
-            if (const char* e = getenv("DR3HIP_TILE_LDS")) lds = atoi(e);      // experiments only
+#ifdef DR3_WARP_EXPERIMENT
+            if (const char* e = getenv("DR3HIP_TILE_LDS")) lds = std::min((std::max(atoi(e), 1024) + 255) & ~255, kWarpTileLdsBytes);      // slice-size sweeps: experiment builds only
+#endif
             hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds, run);
             return hipGetLastError();
         }

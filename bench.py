@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PRE_ROLL_STEPS = int(os.environ.get("DR3_BENCH_PRE_ROLL", "256"))
+PRE_ROLL_STEPS = 256
                              # untimed steady-state pre-roll before the W warm-up steps (about 0.3 s of device time).  The part keeps
                              # settling for longer than round 2's 32 steps allowed on some boxes: 20 timed steps right after them took
                              # 1.19 ms each where 400 took 1.12 (round 3, same process); the metric is a stream's steady state
@@ -326,6 +326,14 @@ def strip_grid_threads(w, h, n_jobs):
     return -(-tx * ty // per) * per * n_jobs * 256
 
 
+def direct_grid_threads(w, h, n_jobs, four_px_lanes):
+    """threads of one warp_perspective_kernel launch (launch_warp in warp_kernels.hip): a wave tile is WaveTile<PXT>::LX lanes x LY rows
+    (DR3_WT4_LOG = 4: 16 lanes of 4 pixels x 4 rows for 8UC1 / 8UC3; DR3_WT1_LOG = 6: 64 one-pixel lanes x 1 row otherwise), a block
+    four of them stacked in y"""
+    lx, ly, pxt = (16, 4, 4) if four_px_lanes else (64, 1, 1)
+    return -(-w // (lx * pxt)) * -(-h // (4 * ly)) * n_jobs * 256
+
+
 def cheap_tile(synth, w, h):
     """4000x3000x3 u8 tile: low-res analytic texture upsampled + deterministic fine pattern
     (content does not influence warp timing; the full analytic generator would take minutes)"""
@@ -457,7 +465,7 @@ def main(argv=None):
     ctx.profile_enable(False)
 
     # ---- result check against the oracle (rank 0, pair 0) -------------------------------------------
-    verified, raster = None, None
+    verified, raster, orders = None, None, None
     tracked_frac = float(d_st.download((B, N_PTS), np.uint8).mean())
     if dist.rank == 0 and have_gpu:
         from oracle import oracle as O
@@ -469,6 +477,16 @@ def main(argv=None):
         # the same pair in OpenCV's scalar summation order: north_star's 1e-3 px bar (oracle.order_agreement says how it is read)
         r_res = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_RASTER, want_iters=True)
         raster = O.order_agreement((g_xy, g_st, None, o_L, o_it), r_res, po, 1e-3)
+        # ... and in the order an x86-64 OpenCV 3.x build executes (LKTrackerInvoker's CV_SSE2 blocks): what the reference's CPU path
+        # computes behind src/initialization.cpp:608-613.  The third pair (OpenCV's two builds against each other) says how much of a
+        # deviation is the summation order's own
+        s_res = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_SSE2, want_iters=True)
+        orders = {"kernel_vs_sse2": O.order_agreement((g_xy, g_st, None, o_L, o_it), s_res, po, 1e-3),
+                  "kernel_vs_raster": raster,
+                  "raster_vs_sse2": O.order_agreement(r_res, s_res, po, 1e-3),
+                  "note": "pair 0 of the timed launches; kernel = the GPU's output (equal to the kernel-order oracle bit for bit), sse2 = the "
+                          "summation order of OpenCV 3.x's x86-64 build (oracle ORDER_SSE2), raster = its scalar build; all four BASELINE "
+                          "configurations: profiles/r04_v1/order_agreement.json (tools/order_agreement.py)"}
 
     # ---- how many Gauss-Newton iteration-levels a point takes, and the slowest point of a lock-step group (what a wave executes):
     # one more launch, untimed, that also writes the iteration counts
@@ -603,6 +621,8 @@ def main(argv=None):
             "n_gpus": dist.world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "pre_roll_steps": PRE_ROLL_STEPS,
+            "steady_state_note": "value is a stream's steady state: %d untimed pre-roll steps precede the %d warm-up steps" % (PRE_ROLL_STEPS, args.warmup),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -620,6 +640,9 @@ def main(argv=None):
             "raster_within_1e-3_frac": None if raster is None else raster["within_tol_frac"],
             "raster_max_dev_px": None if raster is None else raster["max_dev_px"],
             "raster_order_agreement": raster,
+            "sse2_within_1e-3_frac": None if orders is None else orders["kernel_vs_sse2"]["within_tol_frac"],
+            "sse2_converged_max_dev_px": None if orders is None else orders["kernel_vs_sse2"]["converged_max_dev_px"],
+            "summation_order_agreement": orders,
             "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)",
                          "bound": "hbm", "achieved": ach_l0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach_l0 / HBM_PEAK_GBPS, "traffic": traffic_l0,
@@ -1132,8 +1155,8 @@ def warp_leg(dist, ctx, dr3, synth, sync, steps):
         kname = "warp_tile_8uc3_kernel" if plan["kernel"] == 2 else "warp_perspective_kernel<%d," % typ
         if plan["kernel"] == 2:                              # the strip kernel's grid (launch_warp): 64 x 64 tiles, padded to whole XCD rounds
             gthreads = strip_grid_threads(TW_, TH_, NT_)
-        else:                                                # the direct kernel: 64 x 4 pixels per 256-thread block, one pixel per lane
-            gthreads = -(-TW_ // 64) * -(-TH_ // 4) * NT_ * 256
+        else:                                                # the direct kernel (launch_warp): a 256-thread block of four wave tiles, stacked in y
+            gthreads = direct_grid_threads(TW_, TH_, NT_, typ in (dr3.T_8UC1, dr3.T_8UC3))
         traffic, tsrc = pmc_traffic(kname, 256, "pmc_traffic_warp.json", gthreads)
         res[name] = {"mpix_per_s": mpix, "kernel_ms": k_ms, "verified_vs_oracle": ok, "kernel_plan": plan,
                      "roofline": {"kernel": ("warp_tile_8uc3_kernel (LDS-staged strips)" if plan["kernel"] == 2 else "warp_perspective_kernel<%s>" % name.upper()), "bound": "hbm",

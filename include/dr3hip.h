@@ -174,7 +174,10 @@ int  dr3hip_batch_upload_wait(dr3hip_batch* b);
 int  dr3hip_host_alloc(dr3hip_ctx* ctx, size_t bytes, void** out);
 int  dr3hip_host_free(dr3hip_ctx* ctx, void* p);
 /* Results leave on the context's download stream, behind everything the compute stream has been given so far, while the compute
- * stream goes on (host: pinned memory for a copy that really is asynchronous).  dr3hip_download_wait: all of them have arrived. */
+ * stream goes on (host: pinned memory for a copy that really is asynchronous).  dr3hip_download_wait: all of them have arrived.
+ * The compute stream does NOT wait for the copy: `dev` must not be written again (by a later dr3hip_batch_track, a memset, an
+ * upload ...) until dr3hip_download_wait has returned -- a caller that keeps the compute stream busy alternates two result
+ * buffers and waits one step behind, as INTEGRATION.md's streaming loop and bench.py's stream leg do. */
 int  dr3hip_download_async(dr3hip_ctx* ctx, void* host, const void* dev, size_t bytes);
 int  dr3hip_download_wait(dr3hip_ctx* ctx);
 /* Every level of a slot carries OpenCV's winSize border physically (REFLECT_101 pixels; dr3hip_batch_upload writes level 0's with

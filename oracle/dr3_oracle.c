@@ -157,14 +157,18 @@ static inline int der_at(const lvl_deriv* D, int x, int y, int c)
     return D->d[(size_t)y * D->stride + 2 * x + c];
 }
 
-/* Window-sum accumulator that can emulate either summation order. */
+/* Window-sum accumulator that can emulate the summation orders. */
 typedef struct {
     int   order;
+    int   kind;                   /* WSUM_A / WSUM_B / WSUM_E: which loop of the tracker the sums belong to (matters for DR3O_ORDER_SSE2 only) */
     int   win_w;
     int   blk_shift, lanes;       /* kernel's order: log2(rows per lane-item) and lanes per point (64, 32 = half or 8 = an eighth of a wave) */
     long long lane[3][64];        /* up to three simultaneous sums: the lane-local part is an exact integer sum */
     float acc[3];
+    float q[3][4];                /* SSE2 order: the four f32 lanes of the vector accumulators (A: qA11/qA12/qA22; b: the x / y lanes of qb0, qb1) */
+    int   pend[3][4];             /* SSE2 order, b sums: the first product of a _mm_madd_epi16 pair, waiting for its partner four columns on */
 } wsum;
+enum { WSUM_A = 0, WSUM_B = 1, WSUM_E = 2 };
 
 /* The HIP tracker (3dr_amd/csrc/lk_kernels.hip) tracks a point with a GROUP of lanes, and a lane owns taps of ONE window column.
  * Windows up to 16 x 16 (e.g. the bench's 15x15): an EIGHTH of a wave -- 8 lanes, a lane owns the columns c and c + 8 (32 taps, one
@@ -179,23 +183,46 @@ static int kernel_points_per_wave(int win_w, int win_h)
     return 1;
 }
 
-static void wsum_init(wsum* s, int order, int win_w, int win_h)
+static void wsum_init(wsum* s, int order, int kind, int win_w, int win_h)
 {
     const int ppw = kernel_points_per_wave(win_w, win_h);
-    s->order = order; s->win_w = win_w;
+    s->order = order; s->kind = kind; s->win_w = win_w;
     s->blk_shift = ppw >= 4 ? 4 : 3;
     s->lanes = 64 / ppw;
     memset(s->lane, 0, sizeof(s->lane));
+    memset(s->q, 0, sizeof(s->q));
+    memset(s->pend, 0, sizeof(s->pend));
     s->acc[0] = s->acc[1] = s->acc[2] = 0.f;
 }
 /* Every term of the three LK window sums is an integer (a product of two fixed-point values, or |diff|).
  * RASTER (OpenCV's scalar path): converted to f32 and added in raster order, each add rounding.
  * WAVE64 (the HIP kernel): lane-item q = (ty >> blk_shift) * win_w + tx; lane = q % lanes;
  * the taps of one lane are summed as integers (v_dot2_i32_i16 accumulates exactly; at most 16 taps of < 2^25.1 each, so
- * int32 cannot overflow in the kernel), converted to f32 once, and the lane values go through the f32 tree of wsum_get. */
+ * int32 cannot overflow in the kernel), converted to f32 once, and the lane values go through the f32 tree of wsum_get.
+ * SSE2 (what an x86-64 build of OpenCV 3.0 - 3.4 executes behind src/initialization.cpp:608-613: LKTrackerInvoker's CV_SSE2 blocks,
+ * lkpyramid.cpp; restated from the published source, OpenCV being absent here -- tests/test_oracle_sse2.py replays the intrinsic
+ * sequences with real <emmintrin.h> intrinsics against this bookkeeping):
+ *   A sums (template loop): columns x < (win_w & ~3) go four at a time through _mm_cvtepi32_ps + _mm_mul_ps + _mm_add_ps into a
+ *     4-lane f32 accumulator (lane = x & 3; the f32 product of two converted int16 values equals the converted integer product, both
+ *     being the correctly rounded exact product), running over all rows; the remaining columns of every row go to the scalar accumulator
+ *     in raster order; at the end  iA += ((q[0] + q[1]) + q[2]) + q[3].
+ *   b sums (iteration loop): columns x < (win_w & ~7) go eight at a time: _mm_madd_epi16 adds the products of columns j and j + 4 of
+ *     the chunk exactly in int32 (j = 0..3), _mm_cvtepi32_ps converts the pair sum, and it is added to lane (x: 0, y: 1) of qb0 for
+ *     j = 0, lanes (2, 3) of qb0 for j = 1, lanes (0, 1) of qb1 for j = 2, lanes (2, 3) of qb1 for j = 3; the remaining columns go to
+ *     the scalar accumulators; at the end bbuf = qb0 + qb1 lane-wise and  ib1 += bbuf[0] + bbuf[2], ib2 += bbuf[1] + bbuf[3], i.e.
+ *     ib += (q[0] + q[2]) + (q[1] + q[3]) with q[j] the accumulator pair j feeds.
+ *   err (level-0 residual): scalar in every build -- raster order. */
 static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)
 {
     if (s->order == DR3O_ORDER_RASTER) { s->acc[which] += (float)v; return; }
+    if (s->order == DR3O_ORDER_SSE2) {
+        if (s->kind == WSUM_A && tx < (s->win_w & ~3)) s->q[which][tx & 3] += (float)v;
+        else if (s->kind == WSUM_B && tx < (s->win_w & ~7)) {
+            if ((tx & 7) < 4) s->pend[which][tx & 3] = v;
+            else s->q[which][tx & 3] += (float)(s->pend[which][tx & 3] + v);
+        } else s->acc[which] += (float)v;
+        return;
+    }
     {
         const int q = (ty >> s->blk_shift) * s->win_w + tx;
         s->lane[which][q & (s->lanes - 1)] += v;
@@ -204,6 +231,12 @@ static inline void wsum_add(wsum* s, int which, int tx, int ty, int v)
 static float wsum_get(wsum* s, int which)
 {
     if (s->order == DR3O_ORDER_RASTER) return s->acc[which];
+    if (s->order == DR3O_ORDER_SSE2) {
+        const float* q = s->q[which];
+        if (s->kind == WSUM_A) return s->acc[which] + (((q[0] + q[1]) + q[2]) + q[3]);
+        if (s->kind == WSUM_B) return s->acc[which] + ((q[0] + q[2]) + (q[1] + q[3]));
+        return s->acc[which];
+    }
     {
         /* the HIP kernel's tree (3dr_amd/csrc/lk_kernels.hip, wave_sum2 / wave_sum3 and group_sum2 / group_sum1): whole-wave
          * shape: fold the upper half-wave onto the lower first; whole- and half-wave shapes: fold the upper 16 of the 32 values
@@ -276,7 +309,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
         iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-        wsum_init(&S, order, win_w, win_h);
+        wsum_init(&S, order, WSUM_A, win_w, win_h);
         for (y = 0; y < win_h; ++y) {
             for (x = 0; x < win_w; ++x) {
                 const int X = ipx + x, Y = ipy + y;
@@ -331,7 +364,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-            wsum_init(&S, order, win_w, win_h);
+            wsum_init(&S, order, WSUM_B, win_w, win_h);
             for (y = 0; y < win_h; ++y) {
                 for (x = 0; x < win_w; ++x) {
                     const int X = inx + x, Y = iny + y;
@@ -375,7 +408,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-            wsum_init(&S, order, win_w, win_h);
+            wsum_init(&S, order, WSUM_E, win_w, win_h);
             for (y = 0; y < win_h; ++y) {
                 for (x = 0; x < win_w; ++x) {
                     const int X = inx + x, Y = iny + y;
@@ -390,6 +423,29 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
         }
     }
     next_pt[0] = nx; next_pt[1] = ny;
+}
+
+/* The window sums of one template window (A11, A12, A22 from the int16 gradient pairs dI[h][w][2]) and of one iteration (b1, b2 from
+ * the int16 mismatches diff[h][w] and the same gradients) in a given summation order: the bookkeeping of wsum_add / wsum_get alone, so
+ * that tests can hold it against a replay of OpenCV's intrinsic sequences (oracle/sse2_replay.c). */
+void dr3o_window_sums(const int16_t* dI, const int16_t* diff, int win_w, int win_h, int order, float A[3], float b[2])
+{
+    wsum S;
+    int x, y;
+    wsum_init(&S, order, WSUM_A, win_w, win_h);
+    for (y = 0; y < win_h; ++y)
+        for (x = 0; x < win_w; ++x) {
+            const int ix = dI[2 * (y * win_w + x)], iy = dI[2 * (y * win_w + x) + 1];
+            wsum_add(&S, 0, x, y, ix * ix); wsum_add(&S, 1, x, y, ix * iy); wsum_add(&S, 2, x, y, iy * iy);
+        }
+    A[0] = wsum_get(&S, 0); A[1] = wsum_get(&S, 1); A[2] = wsum_get(&S, 2);
+    wsum_init(&S, order, WSUM_B, win_w, win_h);
+    for (y = 0; y < win_h; ++y)
+        for (x = 0; x < win_w; ++x) {
+            const int d = diff[y * win_w + x];
+            wsum_add(&S, 0, x, y, d * dI[2 * (y * win_w + x)]); wsum_add(&S, 1, x, y, d * dI[2 * (y * win_w + x) + 1]);
+        }
+    b[0] = wsum_get(&S, 0); b[1] = wsum_get(&S, 1);
 }
 
 int dr3o_lk_track_ex(const uint8_t* prev, const uint8_t* next, int w, int h,

@@ -50,6 +50,11 @@ extern "C" {
                                  * else 64 (upper half-wave folded onto the lower first).  Lane partial sums are exact integers converted to
                                  * f32 once; then all: xor butterfly 1,2,4,8 */
 
+#define DR3O_ORDER_SSE2     2  /* what an x86-64 build of OpenCV 3.0 - 3.4 executes (LKTrackerInvoker's CV_SSE2 blocks): A sums in a 4-lane f32
+                                 * accumulator over x-chunks of 4 (+ scalar tail), lanes added ((q0 + q1) + q2) + q3; b sums as _mm_madd_epi16 pairs
+                                 * of columns (j, j + 4) of x-chunks of 8, converted and added into two 4-lane accumulators, (q0 + q2) + (q1 + q3),
+                                 * + scalar tail; err scalar.  dr3_oracle.c, wsum_add */
+
 /* half-sample rounding / addressing modes (src/utils.cpp:382-419) */
 #define DR3O_HALF_TRUNC      0 /* row-aligned, (a+b+c+d)/4 truncating  (scalar :411, NEON :353-372) */
 #define DR3O_HALF_SSE2       1 /* row-aligned, avg(avg(a,c),avg(b,d)) rounding up twice (:337,:340) */
@@ -91,6 +96,9 @@ int  dr3o_lk_track_ex(const uint8_t* prev, const uint8_t* next, int w, int h,
                       const float* prev_xy, float* next_xy, int n,
                       uint8_t* status, float* err, const dr3o_lk_params* p,
                       int order, int n_threads, int* iters);
+
+/* the window sums of one template window / one iteration from given int16 values, in a given order (tests of the order bookkeeping) */
+void dr3o_window_sums(const int16_t* dI, const int16_t* diff, int win_w, int win_h, int order, float A[3], float b[2]);
 
 /* src/utils.cpp:382-419 -- 2x2 box half-sampler, dst size (w/2, h/2) (floor). */
 void dr3o_halfsample_u8(const uint8_t* src, int w, int h, int stride,

@@ -17,7 +17,8 @@ _LIB_PATH = os.environ.get("DR3O_LIB") or os.path.join(_HERE, "libdr3oracle.so")
 T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
 LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
 WARP_INVERSE_MAP = 16
-ORDER_RASTER, ORDER_WAVE64 = 0, 1
+ORDER_RASTER, ORDER_WAVE64, ORDER_SSE2 = 0, 1, 2
+ORDER_NAMES = {ORDER_RASTER: "raster", ORDER_WAVE64: "kernel", ORDER_SSE2: "sse2"}
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
 CRIT_COUNT, CRIT_EPS = 1, 2
 
@@ -95,6 +96,8 @@ def lib():
         L.dr3o_lk_track_ex.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp,
                                        C.POINTER(LKParams), ip, ip, vp]
         L.dr3o_lk_track_ex.restype = ip
+        L.dr3o_window_sums.argtypes = [vp, vp, ip, ip, ip, vp, vp]
+        L.dr3o_window_sums.restype = None
         L.dr3o_halfsample_u8.argtypes = [vp, ip, ip, ip, vp, ip, ip]
         L.dr3o_halfsample_u8.restype = None
         L.dr3o_invert3x3.argtypes = [vp, vp]
@@ -205,6 +208,34 @@ def lk_track(prev, nxt, prev_xy, next_xy0=None, params=None, order=ORDER_RASTER,
     return nxt_xy, status, err, r
 
 
+def window_sums(dI, diff, order):
+    """(A11, A12, A22), (b1, b2) of one window from given int16 gradients dI (h, w, 2) and mismatches diff (h, w) in a summation
+    order: the bookkeeping of the tracker's window sums alone (tests/test_oracle_sse2.py)"""
+    dI = np.ascontiguousarray(dI, np.int16); diff = np.ascontiguousarray(diff, np.int16)
+    h, w = diff.shape
+    A, b = np.zeros(3, np.float32), np.zeros(2, np.float32)
+    lib().dr3o_window_sums(_p(dI), _p(diff), w, h, order, _p(A), _p(b))
+    return A, b
+
+
+def sse2_replay_lib():
+    """oracle/sse2_replay.c: OpenCV's CV_SSE2 accumulation sequences with real intrinsics (x86-64 only); None elsewhere"""
+    import platform
+    if platform.machine() not in ("x86_64", "AMD64"):
+        return None
+    path = os.path.join(_HERE, "libsse2_replay.so")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "sse2_replay.c")):
+        if _under_profiler():
+            return None
+        subprocess.check_call(["make", "-C", _HERE, "libsse2_replay.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(path)
+    L.sse2_replay_A.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sse2_replay_A.restype = None
+    L.sse2_replay_B.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sse2_replay_B.restype = None
+    return L
+
+
 def effective_criteria(p):
     """TermCriteria clamping of SparsePyrLKOpticalFlowImpl::calc (SURVEY A-3): (max_count, eps)"""
     mc = min(max(int(p.max_iters), 0), 100) if p.crit_type & 1 else 30
@@ -238,6 +269,8 @@ def order_agreement(a, b, params, tol_px=1e-3):
             "max_dev_px": float(d[both].max()) if both.any() else 0.0,
             "exit_flipped": int(flipped.sum()), "exit_flipped_max_dev_px": float(d[flipped].max()) if flipped.any() else 0.0,
             "clamped": int(clamped.sum()), "clamped_max_dev_px": float(d[clamped].max()) if clamped.any() else 0.0,
+            "converged_max_dev_px": float(d[both & ~clamped].max()) if (both & ~clamped).any() else 0.0,
+            "converged_within_tol": bool((d[both & ~clamped] <= tol_px).all()) if (both & ~clamped).any() else True,
             "eps": eps, "max_count": mc, "tol_px": tol_px}
 
 
