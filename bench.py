@@ -1539,31 +1539,41 @@ def cpu_baseline(frames, pts, seconds, with_warp, synth):
                 O.use_library(None)
         except OSError:
             O.use_library(None)
-    O.lk_track(frames[0], frames[1], pts, None, po, n_threads=cores)          # warm-up
-    t0 = time.perf_counter()
-    n_pairs = 0
-    while True:
-        i = n_pairs % (len(frames) - 1)
-        O.lk_track(frames[i], frames[i + 1], pts, None, po, n_threads=cores)
-        n_pairs += 1
-        if time.perf_counter() - t0 > seconds or n_pairs >= 4096:
-            break
-    el = time.perf_counter() - t0
-    # the same call on ONE thread (SURVEY 8d asks for both), a quarter of the time budget
-    t1 = time.perf_counter()
-    n1 = 0
-    while True:
-        i = n1 % (len(frames) - 1)
-        O.lk_track(frames[i], frames[i + 1], pts, None, po, n_threads=1)
-        n1 += 1
-        if time.perf_counter() - t1 > max(2.0, seconds / 4) or n1 >= 1024:
-            break
-    el1 = time.perf_counter() - t1
-    out = {"value": n_pairs * len(pts) / el, "unit": "keypoints/s", "cores": cores, "kind": "port",
-           "single_thread_value": n1 * len(pts) / el1, "single_thread_sample": "%d frame pairs, %.1f s" % (n1, el1),
+    # two organisations of the same computation, identical results (tests/test_oracle_opt.py): the readable port (per-tap index
+    # reflection, 25-tap pyrDown, OpenCV's scalar summation order) and "port-opt" (separable pyrDown, levels padded once, the window loops
+    # on the SSE2 intrinsic sequences of OpenCV's x86-64 build, its summation order).  `value` is the FASTER one: the >= 50x target is
+    # quoted against the less flattering denominator.
+    def rate(opt, order, threads, budget, cap):
+        O.lk_track(frames[0], frames[1], pts, None, po, order=order, n_threads=threads, opt=opt)          # warm-up
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            i = k % (len(frames) - 1)
+            O.lk_track(frames[i], frames[i + 1], pts, None, po, order=order, n_threads=threads, opt=opt)
+            k += 1
+            if time.perf_counter() - t0 > budget or k >= cap:
+                break
+        el_ = time.perf_counter() - t0
+        return k * len(pts) / el_, k, el_
+
+    same = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_SSE2, n_threads=cores, opt=True)
+    plain = O.lk_track(frames[0], frames[1], pts, None, po, order=O.ORDER_SSE2, n_threads=cores)
+    opt_ok = bool(np.array_equal(same[0].view(np.uint32), plain[0].view(np.uint32)) and np.array_equal(same[1], plain[1]) and
+                  np.array_equal(same[2].view(np.uint32), plain[2].view(np.uint32)))
+    v_opt, n_pairs, el = rate(True, O.ORDER_SSE2, cores, seconds * 0.45, 8192)
+    v_opt1, n1, el1 = rate(True, O.ORDER_SSE2, 1, max(2.0, seconds * 0.15), 2048)
+    v_port, n_p, el_p = rate(False, O.ORDER_RASTER, cores, seconds * 0.25, 4096)
+    v_port1, n_p1, el_p1 = rate(False, O.ORDER_RASTER, 1, max(2.0, seconds * 0.15), 1024)
+    out = {"value": v_opt, "unit": "keypoints/s", "cores": cores, "kind": "port",
+           "variant": "port-opt: dr3o_lk_track_opt (separable pyrDown, padded levels, SSE2 window loops in OpenCV's x86-64 summation order)",
+           "port_opt_equals_port_bit_for_bit": opt_ok,
+           "single_thread_value": v_opt1, "single_thread_sample": "%d frame pairs, %.1f s" % (n1, el1),
+           "readable_port": {"value": v_port, "cores": cores, "single_thread_value": v_port1,
+                             "sample": "%d frame pairs, %.1f s (all cores); %d, %.1f s (one thread)" % (n_p, el_p, n_p1, el_p1),
+                             "note": "dr3o_lk_track_ex: the checker's readable form (index reflection per tap, 25-tap pyrDown, scalar order)"},
            "cpu_model": cpu_model(), "build": build,
-           "sample": "%d frame pairs x %d points of the same stream, oracle dr3o_lk_track (pyramids + Scharr + "
-                     "tracker per pair, OpenMP over rows/points), %.1f s" % (n_pairs, len(pts), el)}
+           "sample": "%d frame pairs x %d points of the same stream, one call per pair (both Gaussian pyramids + Scharr + tracker, as "
+                     "src/initialization.cpp:608 does), OpenMP over rows / points, %.1f s" % (n_pairs, len(pts), el)}
     try:                                                 # the real thing, where a cv2 module happens to exist (it does not in this image)
         import cv2
         crit = (cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, MAX_ITERS, EPS)

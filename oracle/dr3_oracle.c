@@ -9,6 +9,7 @@
 #include "dr3_oracle.h"
 
 #include <limits.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -516,6 +517,398 @@ int dr3o_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h,
 {
     return dr3o_lk_track_ex(prev, next, w, h, prev_stride, next_stride, prev_xy, next_xy, n,
                             status, err, p, order, n_threads, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* "port-opt": the same results, computed the way an optimised CPU library computes them       */
+/* ------------------------------------------------------------------------------------------ */
+/* dr3o_lk_track_opt returns exactly what dr3o_lk_track_ex returns (tests/test_oracle_opt.py: bit for bit, every order), organised
+ * the way OpenCV organises the work instead of the way that is easiest to read: pyrDown separable with a ring of horizontally
+ * filtered rows, Scharr through two row buffers, every level copied once into a plane padded by winSize (REFLECT_101 pixels, zero
+ * derivatives -- buildOpticalFlowPyramid's layout) so that the tracker's windows are plain pointers with no per-tap reflection, and,
+ * on x86-64 in DR3O_ORDER_SSE2, the window loops on the SSE2 intrinsic sequences of LKTrackerInvoker.  It exists so that bench.py's
+ * cpu_baseline has a less flattering denominator than the readable port (round 3's verdict, weak #7); the readable functions above
+ * stay the checker. */
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+static void pyr_down_u8_fast(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dstride)
+{
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    if (sw < 5 || sh < 3) { dr3o_pyr_down_u8(src, sw, sh, sstride, dst, dstride); return; }
+#pragma omp parallel
+    {
+        int* ring = (int*)malloc((size_t)5 * dw * sizeof(int));
+        int tag[5] = {-1, -1, -1, -1, -1};
+        int y;
+#pragma omp for schedule(static)
+        for (y = 0; y < dh; ++y) {
+            const int* rk[5];
+            int k, x;
+            for (k = 0; k < 5; ++k) {
+                const int sy = reflect101(2 * y + k - 2, sh), slot = sy % 5;
+                int* r = ring + (size_t)slot * dw;
+                if (tag[slot] != sy) {
+                    const uint8_t* s = src + (size_t)sy * sstride;
+                    const int x_hi = (sw - 3) / 2;          /* last x with 2x + 2 <= sw - 1 */
+                    tag[slot] = sy;
+                    r[0] = s[0] * 6 + (s[reflect101(-1, sw)] + s[1]) * 4 + s[reflect101(-2, sw)] + s[2];
+                    for (x = 1; x <= x_hi; ++x)
+                        r[x] = s[2 * x] * 6 + (s[2 * x - 1] + s[2 * x + 1]) * 4 + s[2 * x - 2] + s[2 * x + 2];
+                    for (; x < dw; ++x)
+                        r[x] = s[reflect101(2 * x, sw)] * 6 + (s[reflect101(2 * x - 1, sw)] + s[reflect101(2 * x + 1, sw)]) * 4 +
+                               s[reflect101(2 * x - 2, sw)] + s[reflect101(2 * x + 2, sw)];
+                }
+                rk[k] = r;
+            }
+            {
+                uint8_t* d = dst + (size_t)y * dstride;
+                const int *r0 = rk[0], *r1 = rk[1], *r2 = rk[2], *r3 = rk[3], *r4 = rk[4];
+                for (x = 0; x < dw; ++x)
+                    d[x] = (uint8_t)((r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x] + 128) >> 8);
+            }
+        }
+        free(ring);
+    }
+}
+
+/* Scharr into a plane padded by (pad_x, pad_y) zeros (calloc'ed by the caller); d0 = the interior origin, stride in int16 */
+static void scharr_s16_fast(const uint8_t* src, int w, int h, int stride, int16_t* d0, int dstride)
+{
+    if (w < 2 || h < 2) { dr3o_scharr_s16(src, w, h, stride, d0, dstride); return; }
+#pragma omp parallel
+    {
+        int* t0 = (int*)malloc((size_t)(w + 2) * sizeof(int));      /* smoothed in y, with the REFLECT_101 columns at -1 and w */
+        int* t1 = (int*)malloc((size_t)(w + 2) * sizeof(int));      /* differentiated in y */
+        int y;
+#pragma omp for schedule(static)
+        for (y = 0; y < h; ++y) {
+            const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : 1) * stride;
+            const uint8_t* r1 = src + (size_t)y * stride;
+            const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : h - 2) * stride;
+            int16_t* d = d0 + (size_t)y * dstride;
+            int x;
+            for (x = 0; x < w; ++x) { t0[x + 1] = (r0[x] + r2[x]) * 3 + r1[x] * 10; t1[x + 1] = r2[x] - r0[x]; }
+            t0[0] = t0[2]; t1[0] = t1[2]; t0[w + 1] = t0[w - 1]; t1[w + 1] = t1[w - 1];
+            for (x = 0; x < w; ++x) {
+                d[2 * x]     = (int16_t)(t0[x + 2] - t0[x]);
+                d[2 * x + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
+            }
+        }
+        free(t0); free(t1);
+    }
+}
+
+typedef struct { const uint8_t* img; const int16_t* der; int w, h, stride, dstride; } plvl;   /* origins of the interiors of padded planes */
+
+static uint8_t* pad_reflect101(const uint8_t* src, int w, int h, int stride, int px, int py, int* pstride)
+{
+    const int pw = w + 2 * px, ph = h + 2 * py;
+    uint8_t* out = (uint8_t*)malloc((size_t)pw * ph + 16);
+    int y;
+#pragma omp parallel for schedule(static)
+    for (y = 0; y < ph; ++y) {
+        const uint8_t* s = src + (size_t)reflect101(y - py, h) * stride;
+        uint8_t* d = out + (size_t)y * pw;
+        int x;
+        for (x = 0; x < px; ++x) d[x] = s[reflect101(x - px, w)];
+        memcpy(d + px, s, (size_t)w);
+        for (x = 0; x < px; ++x) d[px + w + x] = s[reflect101(w + x, w)];
+    }
+    *pstride = pw;
+    return out;
+}
+
+static void lk_track_point_fast(const plvl* I, const plvl* J, int max_level, const float* prev_pt, float* next_pt,
+                                uint8_t* status, float* err, int win_w, int win_h, int max_count, double epsilon,
+                                int flags, double min_eig_threshold, int order, int16_t* Ibuf, int16_t* dIbuf, int* iters)
+{
+    const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    float nx = next_pt[0], ny = next_pt[1];
+    int level;
+#if defined(__SSE2__)
+    const int simd = order == DR3O_ORDER_SSE2;
+#else
+    const int simd = 0;
+#endif
+    *status = 1; *err = 0.f;
+    for (level = max_level; level >= 0; --level) {
+        const plvl* Il = &I[level];
+        const plvl* Jl = &J[level];
+        const int sI = Il->stride, sJ = Jl->stride, sD = Il->dstride;
+        const float scale = (float)(1. / (1 << level));
+        float px = prev_pt[0] * scale, py = prev_pt[1] * scale, cx, cy, a, b, A11, A12, A22, D, minEig, pdx = 0.f, pdy = 0.f;
+        int ipx, ipy, x, y, j, iw00, iw01, iw10, iw11;
+        wsum S;
+
+        if (iters) iters[level] = 0;
+        if (level == max_level) {
+            if (flags & DR3O_LK_USE_INITIAL_FLOW) { cx = nx * scale; cy = ny * scale; } else { cx = px; cy = py; }
+        } else { cx = nx * 2.f; cy = ny * 2.f; }
+        nx = cx; ny = cy;
+        px -= half_x; py -= half_y;
+        ipx = cv_floor_f(px); ipy = cv_floor_f(py);
+        if (ipx < -win_w || ipx >= Il->w || ipy < -win_h || ipy >= Il->h) {
+            if (level == 0) { *status = 0; *err = 0.f; }
+            continue;
+        }
+        a = px - ipx; b = py - ipy;
+        iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+        iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+        iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+        iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+        if (simd) {
+#if defined(__SSE2__)
+            const __m128i qw0 = _mm_set1_epi32(iw00 + (int)((unsigned)iw01 << 16)), qw1 = _mm_set1_epi32(iw10 + (int)((unsigned)iw11 << 16));
+            const __m128i z = _mm_setzero_si128(), qdelta_d = _mm_set1_epi32(1 << (W_BITS - 1)), qdelta = _mm_set1_epi32(1 << (W_BITS - 5 - 1));
+            __m128 qA11 = _mm_setzero_ps(), qA12 = _mm_setzero_ps(), qA22 = _mm_setzero_ps();
+            float iA11 = 0.f, iA12 = 0.f, iA22 = 0.f, b11[4], b12[4], b22[4];
+            for (y = 0; y < win_h; ++y) {
+                const uint8_t* src = Il->img + (ptrdiff_t)(ipy + y) * sI + ipx;
+                const int16_t* dsrc = Il->der + (ptrdiff_t)(ipy + y) * sD + 2 * ipx;
+                int16_t* Iptr = Ibuf + y * win_w;
+                int16_t* dIptr = dIbuf + 2 * y * win_w;
+                x = 0;
+                for (; x <= win_w - 4; x += 4, dsrc += 4 * 2, dIptr += 4 * 2) {
+                    int t32[4];
+                    __m128i v00, v01, v10, v11, t0, t1;
+                    memcpy(&t32[0], src + x, 4); memcpy(&t32[1], src + x + 1, 4); memcpy(&t32[2], src + x + sI, 4); memcpy(&t32[3], src + x + sI + 1, 4);
+                    v00 = _mm_unpacklo_epi8(_mm_cvtsi32_si128(t32[0]), z);
+                    v01 = _mm_unpacklo_epi8(_mm_cvtsi32_si128(t32[1]), z);
+                    v10 = _mm_unpacklo_epi8(_mm_cvtsi32_si128(t32[2]), z);
+                    v11 = _mm_unpacklo_epi8(_mm_cvtsi32_si128(t32[3]), z);
+                    t0 = _mm_add_epi32(_mm_madd_epi16(_mm_unpacklo_epi16(v00, v01), qw0), _mm_madd_epi16(_mm_unpacklo_epi16(v10, v11), qw1));
+                    t0 = _mm_srai_epi32(_mm_add_epi32(t0, qdelta), W_BITS - 5);
+                    _mm_storel_epi64((__m128i*)(Iptr + x), _mm_packs_epi32(t0, t0));
+                    v00 = _mm_loadu_si128((const __m128i*)(dsrc));
+                    v01 = _mm_loadu_si128((const __m128i*)(dsrc + 2));
+                    v10 = _mm_loadu_si128((const __m128i*)(dsrc + sD));
+                    v11 = _mm_loadu_si128((const __m128i*)(dsrc + sD + 2));
+                    t0 = _mm_add_epi32(_mm_madd_epi16(_mm_unpacklo_epi16(v00, v01), qw0), _mm_madd_epi16(_mm_unpacklo_epi16(v10, v11), qw1));
+                    t1 = _mm_add_epi32(_mm_madd_epi16(_mm_unpackhi_epi16(v00, v01), qw0), _mm_madd_epi16(_mm_unpackhi_epi16(v10, v11), qw1));
+                    t0 = _mm_srai_epi32(_mm_add_epi32(t0, qdelta_d), W_BITS);
+                    t1 = _mm_srai_epi32(_mm_add_epi32(t1, qdelta_d), W_BITS);
+                    v00 = _mm_packs_epi32(t0, t1);
+                    _mm_storeu_si128((__m128i*)dIptr, v00);
+                    t0 = _mm_srai_epi32(v00, 16);
+                    t1 = _mm_srai_epi32(_mm_slli_epi32(v00, 16), 16);
+                    {
+                        const __m128 fy = _mm_cvtepi32_ps(t0), fx = _mm_cvtepi32_ps(t1);
+                        qA22 = _mm_add_ps(qA22, _mm_mul_ps(fy, fy));
+                        qA12 = _mm_add_ps(qA12, _mm_mul_ps(fx, fy));
+                        qA11 = _mm_add_ps(qA11, _mm_mul_ps(fx, fx));
+                    }
+                }
+                for (; x < win_w; ++x, dsrc += 2, dIptr += 2) {
+                    const int ival = DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + sI] * iw10 + src[x + sI + 1] * iw11, W_BITS - 5);
+                    const int ixval = DESCALE(dsrc[0] * iw00 + dsrc[2] * iw01 + dsrc[sD] * iw10 + dsrc[sD + 2] * iw11, W_BITS);
+                    const int iyval = DESCALE(dsrc[1] * iw00 + dsrc[3] * iw01 + dsrc[sD + 1] * iw10 + dsrc[sD + 3] * iw11, W_BITS);
+                    Iptr[x] = (int16_t)ival; dIptr[0] = (int16_t)ixval; dIptr[1] = (int16_t)iyval;
+                    iA11 += (float)(ixval * ixval); iA12 += (float)(ixval * iyval); iA22 += (float)(iyval * iyval);
+                }
+            }
+            _mm_storeu_ps(b11, qA11); _mm_storeu_ps(b12, qA12); _mm_storeu_ps(b22, qA22);
+            iA11 += b11[0] + b11[1] + b11[2] + b11[3];
+            iA12 += b12[0] + b12[1] + b12[2] + b12[3];
+            iA22 += b22[0] + b22[1] + b22[2] + b22[3];
+            A11 = iA11 * FLT_SCALE; A12 = iA12 * FLT_SCALE; A22 = iA22 * FLT_SCALE;
+#endif
+        } else {
+            wsum_init(&S, order, WSUM_A, win_w, win_h);
+            for (y = 0; y < win_h; ++y) {
+                const uint8_t* src = Il->img + (ptrdiff_t)(ipy + y) * sI + ipx;
+                const int16_t* dsrc = Il->der + (ptrdiff_t)(ipy + y) * sD + 2 * ipx;
+                for (x = 0; x < win_w; ++x, dsrc += 2) {
+                    const int ival = DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + sI] * iw10 + src[x + sI + 1] * iw11, W_BITS - 5);
+                    const int ixval = DESCALE(dsrc[0] * iw00 + dsrc[2] * iw01 + dsrc[sD] * iw10 + dsrc[sD + 2] * iw11, W_BITS);
+                    const int iyval = DESCALE(dsrc[1] * iw00 + dsrc[3] * iw01 + dsrc[sD + 1] * iw10 + dsrc[sD + 3] * iw11, W_BITS);
+                    Ibuf[y * win_w + x] = (int16_t)ival;
+                    dIbuf[2 * (y * win_w + x)] = (int16_t)ixval; dIbuf[2 * (y * win_w + x) + 1] = (int16_t)iyval;
+                    if (order == DR3O_ORDER_RASTER) { S.acc[0] += (float)(ixval * ixval); S.acc[1] += (float)(ixval * iyval); S.acc[2] += (float)(iyval * iyval); }
+                    else { wsum_add(&S, 0, x, y, ixval * ixval); wsum_add(&S, 1, x, y, ixval * iyval); wsum_add(&S, 2, x, y, iyval * iyval); }
+                }
+            }
+            A11 = wsum_get(&S, 0) * FLT_SCALE; A12 = wsum_get(&S, 1) * FLT_SCALE; A22 = wsum_get(&S, 2) * FLT_SCALE;
+        }
+
+        D = A11 * A22 - A12 * A12;
+        minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
+        if (flags & DR3O_LK_GET_MIN_EIGENVALS) *err = minEig;
+        if ((double)minEig < min_eig_threshold || D < FLT_EPSILON) {
+            if (level == 0) *status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        cx -= half_x; cy -= half_y;
+
+        for (j = 0; j < max_count; ++j) {
+            const int inx = cv_floor_f(cx), iny = cv_floor_f(cy);
+            float b1, b2, dx, dy;
+            if (inx < -win_w || inx >= Jl->w || iny < -win_h || iny >= Jl->h) {
+                if (level == 0) *status = 0;
+                break;
+            }
+            if (iters) iters[level] = j + 1;
+            a = cx - inx; b = cy - iny;
+            iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            if (simd) {
+#if defined(__SSE2__)
+                const __m128i qw0 = _mm_set1_epi32(iw00 + (int)((unsigned)iw01 << 16)), qw1 = _mm_set1_epi32(iw10 + (int)((unsigned)iw11 << 16));
+                const __m128i z = _mm_setzero_si128(), qdelta = _mm_set1_epi32(1 << (W_BITS - 5 - 1));
+                __m128 qb0 = _mm_setzero_ps(), qb1 = _mm_setzero_ps();
+                float ib1 = 0.f, ib2 = 0.f, bbuf[4];
+                for (y = 0; y < win_h; ++y) {
+                    const uint8_t* Jptr = Jl->img + (ptrdiff_t)(iny + y) * sJ + inx;
+                    const int16_t* Iptr = Ibuf + y * win_w;
+                    const int16_t* dIptr = dIbuf + 2 * y * win_w;
+                    x = 0;
+                    for (; x <= win_w - 8; x += 8, dIptr += 8 * 2) {
+                        __m128i diff0 = _mm_loadu_si128((const __m128i*)(Iptr + x)), diff1;
+                        __m128i v00 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x)), z);
+                        __m128i v01 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + 1)), z);
+                        __m128i v10 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + sJ)), z);
+                        __m128i v11 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + sJ + 1)), z);
+                        __m128i t0 = _mm_add_epi32(_mm_madd_epi16(_mm_unpacklo_epi16(v00, v01), qw0), _mm_madd_epi16(_mm_unpacklo_epi16(v10, v11), qw1));
+                        __m128i t1 = _mm_add_epi32(_mm_madd_epi16(_mm_unpackhi_epi16(v00, v01), qw0), _mm_madd_epi16(_mm_unpackhi_epi16(v10, v11), qw1));
+                        t0 = _mm_srai_epi32(_mm_add_epi32(t0, qdelta), W_BITS - 5);
+                        t1 = _mm_srai_epi32(_mm_add_epi32(t1, qdelta), W_BITS - 5);
+                        diff0 = _mm_subs_epi16(_mm_packs_epi32(t0, t1), diff0);
+                        diff1 = _mm_unpackhi_epi16(diff0, diff0);
+                        diff0 = _mm_unpacklo_epi16(diff0, diff0);
+                        v00 = _mm_loadu_si128((const __m128i*)(dIptr));
+                        v01 = _mm_loadu_si128((const __m128i*)(dIptr + 8));
+                        v10 = _mm_unpacklo_epi16(v00, v01);
+                        v11 = _mm_unpackhi_epi16(v00, v01);
+                        v00 = _mm_unpacklo_epi16(diff0, diff1);
+                        v01 = _mm_unpackhi_epi16(diff0, diff1);
+                        v00 = _mm_madd_epi16(v00, v10);
+                        v11 = _mm_madd_epi16(v01, v11);
+                        qb0 = _mm_add_ps(qb0, _mm_cvtepi32_ps(v00));
+                        qb1 = _mm_add_ps(qb1, _mm_cvtepi32_ps(v11));
+                    }
+                    for (; x < win_w; ++x, dIptr += 2) {
+                        const int diff = DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + sJ] * iw10 + Jptr[x + sJ + 1] * iw11, W_BITS - 5) - Iptr[x];
+                        ib1 += (float)(diff * dIptr[0]); ib2 += (float)(diff * dIptr[1]);
+                    }
+                }
+                _mm_storeu_ps(bbuf, _mm_add_ps(qb0, qb1));
+                ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3];
+                b1 = ib1 * FLT_SCALE; b2 = ib2 * FLT_SCALE;
+#endif
+            } else {
+                wsum_init(&S, order, WSUM_B, win_w, win_h);
+                for (y = 0; y < win_h; ++y) {
+                    const uint8_t* Jptr = Jl->img + (ptrdiff_t)(iny + y) * sJ + inx;
+                    const int16_t* Iptr = Ibuf + y * win_w;
+                    const int16_t* dIptr = dIbuf + 2 * y * win_w;
+                    for (x = 0; x < win_w; ++x, dIptr += 2) {
+                        const int diff = DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + sJ] * iw10 + Jptr[x + sJ + 1] * iw11, W_BITS - 5) - Iptr[x];
+                        if (order == DR3O_ORDER_RASTER) { S.acc[0] += (float)(diff * dIptr[0]); S.acc[1] += (float)(diff * dIptr[1]); }
+                        else { wsum_add(&S, 0, x, y, diff * dIptr[0]); wsum_add(&S, 1, x, y, diff * dIptr[1]); }
+                    }
+                }
+                b1 = wsum_get(&S, 0) * FLT_SCALE; b2 = wsum_get(&S, 1) * FLT_SCALE;
+            }
+            dx = (float)((A12 * b2 - A22 * b1) * D);
+            dy = (float)((A12 * b1 - A11 * b2) * D);
+            cx += dx; cy += dy;
+            nx = cx + half_x; ny = cy + half_y;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        if (*status && level == 0 && !(flags & DR3O_LK_GET_MIN_EIGENVALS)) {
+            const float fx = nx - half_x, fy = ny - half_y;
+            const int inx = cv_floor_f(fx), iny = cv_floor_f(fy);
+            if (inx < -win_w || inx >= Jl->w || iny < -win_h || iny >= Jl->h) { *status = 0; continue; }
+            a = fx - inx; b = fy - iny;
+            iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            wsum_init(&S, order, WSUM_E, win_w, win_h);
+            for (y = 0; y < win_h; ++y) {
+                const uint8_t* Jptr = Jl->img + (ptrdiff_t)(iny + y) * sJ + inx;
+                const int16_t* Iptr = Ibuf + y * win_w;
+                for (x = 0; x < win_w; ++x) {
+                    const int diff = DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + sJ] * iw10 + Jptr[x + sJ + 1] * iw11, W_BITS - 5) - Iptr[x];
+                    wsum_add(&S, 0, x, y, diff < 0 ? -diff : diff);
+                }
+            }
+            *err = wsum_get(&S, 0) * 1.f / (float)(32 * win_w * win_h);
+        }
+    }
+    next_pt[0] = nx; next_pt[1] = ny;
+}
+
+int dr3o_lk_track_opt(const uint8_t* prev, const uint8_t* next, int w, int h, int prev_stride, int next_stride,
+                      const float* prev_xy, float* next_xy, int n, uint8_t* status, float* err, const dr3o_lk_params* p,
+                      int order, int n_threads, int* iters)
+{
+    enum { MAXL = 16 };
+    plvl I[MAXL], J[MAXL];
+    uint8_t *ibuf[MAXL], *jbuf[MAXL], *ipad[MAXL], *jpad[MAXL];
+    int16_t* dpad[MAXL];
+    const uint8_t *isrc[MAXL], *jsrc[MAXL];
+    int lw[MAXL], lh[MAXL], lstr[MAXL], jstr[MAXL];
+    int max_level, l, i, max_count;
+    double epsilon;
+
+    if (!prev || !next || !p || w <= 0 || h <= 0 || n < 0) return -1;
+    if (p->max_level < 0 || p->max_level >= MAXL || p->win_w <= 2 || p->win_h <= 2) return -2;
+    set_threads(n_threads);
+    max_level = dr3o_lk_effective_max_level(w, h, p->win_w, p->win_h, p->max_level);
+    max_count = (p->crit_type & 1) ? (p->max_iters < 0 ? 0 : p->max_iters > 100 ? 100 : p->max_iters) : 30;
+    epsilon   = (p->crit_type & 2) ? (p->eps < 0. ? 0. : p->eps > 10. ? 10. : p->eps) : 0.01;
+    epsilon *= epsilon;
+
+    memset(ibuf, 0, sizeof(ibuf)); memset(jbuf, 0, sizeof(jbuf));
+    isrc[0] = prev; jsrc[0] = next; lw[0] = w; lh[0] = h; lstr[0] = prev_stride; jstr[0] = next_stride;
+    for (l = 1; l <= max_level; ++l) {
+        lw[l] = (lw[l - 1] + 1) / 2; lh[l] = (lh[l - 1] + 1) / 2; lstr[l] = jstr[l] = lw[l];
+        ibuf[l] = (uint8_t*)malloc((size_t)lw[l] * lh[l]);
+        jbuf[l] = (uint8_t*)malloc((size_t)lw[l] * lh[l]);
+        pyr_down_u8_fast(isrc[l - 1], lw[l - 1], lh[l - 1], lstr[l - 1], ibuf[l], lw[l]);
+        pyr_down_u8_fast(jsrc[l - 1], lw[l - 1], lh[l - 1], jstr[l - 1], jbuf[l], lw[l]);
+        isrc[l] = ibuf[l]; jsrc[l] = jbuf[l];
+    }
+    for (l = 0; l <= max_level; ++l) {
+        /* one more column / row of slack than winSize: the SSE2 chunks read 4 or 8 bytes from the last tap's column */
+        const int px = p->win_w + 8, py = p->win_h + 1;
+        int ps, js;
+        const size_t dstride = (size_t)2 * (lw[l] + 2 * px);
+        ipad[l] = pad_reflect101(isrc[l], lw[l], lh[l], lstr[l], px, py, &ps);
+        jpad[l] = pad_reflect101(jsrc[l], lw[l], lh[l], jstr[l], px, py, &js);
+        dpad[l] = (int16_t*)calloc(dstride * (lh[l] + 2 * py) + 16, sizeof(int16_t));
+        I[l].img = ipad[l] + (size_t)py * ps + px; I[l].stride = ps; I[l].w = lw[l]; I[l].h = lh[l];
+        J[l].img = jpad[l] + (size_t)py * js + px; J[l].stride = js; J[l].w = lw[l]; J[l].h = lh[l];
+        I[l].der = dpad[l] + (size_t)py * dstride + 2 * px; I[l].dstride = (int)dstride;
+        J[l].der = NULL; J[l].dstride = 0;
+        scharr_s16_fast(isrc[l], lw[l], lh[l], lstr[l], (int16_t*)I[l].der, (int)dstride);
+    }
+#pragma omp parallel
+    {
+        int16_t* Ibuf  = (int16_t*)malloc(((size_t)p->win_w * p->win_h + 8) * sizeof(int16_t));
+        int16_t* dIbuf = (int16_t*)malloc(((size_t)p->win_w * p->win_h + 8) * 2 * sizeof(int16_t));
+#pragma omp for schedule(dynamic, 16)
+        for (i = 0; i < n; ++i)
+            lk_track_point_fast(I, J, max_level, prev_xy + 2 * i, next_xy + 2 * i, status + i, err + i, p->win_w, p->win_h, max_count, epsilon,
+                                p->flags, p->min_eig_threshold, order, Ibuf, dIbuf, iters ? iters + (size_t)i * (max_level + 1) : NULL);
+        free(Ibuf); free(dIbuf);
+    }
+    for (l = 0; l <= max_level; ++l) { free(ibuf[l]); free(jbuf[l]); free(ipad[l]); free(jpad[l]); free(dpad[l]); }
+    return max_level;
 }
 
 /* ------------------------------------------------------------------------------------------ */

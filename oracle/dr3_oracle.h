@@ -97,6 +97,15 @@ int  dr3o_lk_track_ex(const uint8_t* prev, const uint8_t* next, int w, int h,
                       uint8_t* status, float* err, const dr3o_lk_params* p,
                       int order, int n_threads, int* iters);
 
+/* "port-opt": dr3o_lk_track_ex's results bit for bit (every order), organised the way an optimised library organises the work --
+ * separable pyrDown, padded levels without per-tap reflection, SSE2 window loops in DR3O_ORDER_SSE2 on x86-64.  bench.py's cpu_baseline
+ * times it beside the readable port. */
+int  dr3o_lk_track_opt(const uint8_t* prev, const uint8_t* next, int w, int h,
+                       int prev_stride, int next_stride,
+                       const float* prev_xy, float* next_xy, int n,
+                       uint8_t* status, float* err, const dr3o_lk_params* p,
+                       int order, int n_threads, int* iters);
+
 /* the window sums of one template window / one iteration from given int16 values, in a given order (tests of the order bookkeeping) */
 void dr3o_window_sums(const int16_t* dI, const int16_t* diff, int win_w, int win_h, int order, float A[3], float b[2]);
 

@@ -96,6 +96,8 @@ def lib():
         L.dr3o_lk_track_ex.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp,
                                        C.POINTER(LKParams), ip, ip, vp]
         L.dr3o_lk_track_ex.restype = ip
+        L.dr3o_lk_track_opt.argtypes = L.dr3o_lk_track_ex.argtypes
+        L.dr3o_lk_track_opt.restype = ip
         L.dr3o_window_sums.argtypes = [vp, vp, ip, ip, ip, vp, vp]
         L.dr3o_window_sums.restype = None
         L.dr3o_halfsample_u8.argtypes = [vp, ip, ip, ip, vp, ip, ip]
@@ -184,8 +186,9 @@ def lk_params(win=(21, 21), max_level=3, max_iters=30, eps=0.01, crit_type=CRIT_
 
 
 def lk_track(prev, nxt, prev_xy, next_xy0=None, params=None, order=ORDER_RASTER, n_threads=0,
-             want_iters=False):
-    """cv::calcOpticalFlowPyrLK restatement.  Returns (next_xy, status, err, eff_max_level[, iters])."""
+             want_iters=False, opt=False):
+    """cv::calcOpticalFlowPyrLK restatement.  Returns (next_xy, status, err, eff_max_level[, iters]).
+    opt: the "port-opt" organisation of the same computation (dr3o_lk_track_opt: identical results, faster)."""
     prev, nxt = _gray(prev), _gray(nxt)
     assert prev.shape == nxt.shape
     h, w = prev.shape
@@ -198,7 +201,8 @@ def lk_track(prev, nxt, prev_xy, next_xy0=None, params=None, order=ORDER_RASTER,
     err = np.zeros(n, np.float32)
     eff = lk_effective_max_level(w, h, p.win_w, p.win_h, p.max_level)
     iters = np.zeros((n, eff + 1), np.int32) if want_iters else None
-    r = lib().dr3o_lk_track_ex(_p(prev), _p(nxt), w, h, prev.strides[0], nxt.strides[0],
+    fn = lib().dr3o_lk_track_opt if opt else lib().dr3o_lk_track_ex
+    r = fn(_p(prev), _p(nxt), w, h, prev.strides[0], nxt.strides[0],
                                _p(prev_xy), _p(nxt_xy), n, _p(status), _p(err), C.byref(p),
                                order, n_threads, _p(iters) if want_iters else None)
     if r < 0:

@@ -1,6 +1,6 @@
 """The CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY section 5 asked for a sanitizer pass on the CPU
 side; GPU sanitizers are unavailable on the pool).  oracle/Makefile's libdr3oracle_asan.so target is built and the oracle's own
-known-answer tests plus the golden-vector reproduction run against it in a child process with the ASan runtime preloaded:
+known-answer tests, the golden-vector reproduction and the port-opt / SSE2-order tests (padded planes, intrinsic loads) run against it in a child process with the ASan runtime preloaded:
 any out-of-bounds read of a window, pad or table in the restatement, or signed overflow / misaligned access, aborts that child."""
 import os
 import subprocess
@@ -21,7 +21,8 @@ def test_oracle_kat_and_golden_under_asan_ubsan():
                OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_oracle_kat.py"), os.path.join(ROOT, "tests", "test_golden.py"),
-                        "-m", "not gpu"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        os.path.join(ROOT, "tests", "test_oracle_opt.py"), os.path.join(ROOT, "tests", "test_oracle_sse2.py"),
+                        "-m", "not gpu", "--deselect", "tests/test_oracle_opt.py::test_opt_is_faster"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert " passed" in r.stdout
