@@ -28,6 +28,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "dr3hip.h")
 # constants of include/dr3hip.h
 T_8UC1, T_8UC3, T_32FC4, T_8UC4, T_32FC1 = 0, 1, 2, 3, 4
 LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
+LK_DIAG_RESTAGES = 1 << 20      # diagnostic: d_iters carries the re-staging count of every (point, level) in bits 16..31
 LK_LOST_START_OUTSIDE, LK_LOST_MIN_EIG, LK_LOST_ITERATE_OUTSIDE, LK_LOST_RESULT_OUTSIDE = 1, 2, 3, 4
 WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
             cx = nx * 2.f; cy = ny * 2.f;
         }
         nx = cx; ny = cy;
-        int it_count = 0;
+        int it_count = 0, restages = 0;          // restages: how often an iterate left the staged J region (diagnostic, DR3HIP_LK_DIAG_RESTAGES)
 
         px -= half_x; py -= half_y;
         const float fpx = floorf(px), fpy = floorf(py);
@@ -359,9 +359,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                         gbase_t rowD = Dbase;
 #pragma unroll
                         for (int r = 0; r <= NT; ++r)
-                            if (tap_live(r - 1) || tap_live(r)) { ddv[i][r] = ldg<u32x2>(rowD, offD); rowD += dpitch; }
+                            if (tap_live(r - 1) || tap_live(r)) {
+#ifdef LKG_EXP_NODERIV      // TIMING EXPERIMENT ONLY (wrong results): the per-level phase without its 32 derivative loads -- the ceiling of what
+                            // computing Scharr inside the tracker could save (profiles/r04_lk/README.md)
+                                ddv[i][r] = vj[(r + i) % JR];
+#else
+                                ddv[i][r] = ldg<u32x2>(rowD, offD); rowD += dpitch;
+#endif
+                            }
                     }
                     __builtin_amdgcn_sched_barrier(0);           // the scheduler would sink the loads to their uses behind the LDS writes
+#ifdef LKG_EXP_FILLER       // TIMING EXPERIMENT ONLY: LKG_EXP_FILLER extra 4-clock VALU instructions per lane and level on the staged image data -- what
+                            // computing the template's Scharr gradients inside the tracker would add (profiles/r04_lk/README.md)
+                    {
+                        uint32_t f0 = vi[0].x, f1 = vi[0].y, f2 = vi[1].x, f3 = vi[1].y;
+#pragma unroll
+                        for (int q = 0; q < LKG_EXP_FILLER / 4; ++q) {
+                            f0 = __builtin_amdgcn_perm(f0, f1, 0x06050403u); f1 = __builtin_amdgcn_perm(f1, f2, 0x06050403u);
+                            f2 = __builtin_amdgcn_perm(f2, f3, 0x06050403u); f3 = __builtin_amdgcn_perm(f3, f0, 0x06050403u);
+                        }
+                        asm volatile("" :: "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+                    }
+#endif
 #pragma unroll
                     for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = vj[k].x; st[RPR * k * lpd + 1] = vj[k].y; }
                 } else {
@@ -495,6 +514,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                     }
                     __builtin_amdgcn_wave_barrier();
                     dxb = (uint32_t)((inx & ~3) - rx0); dyr = (uint32_t)(iny - ry0);
+                    ++restages;
                 }
                 const Weights W = make_weights(cx - fcx, cy - fcy);
                 const uint32_t base = __umul24(dyr, (unsigned)(4 * lpd));
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                 pdx = dx; pdy = dy;
             }
         }
-        if (a.iters && hl == 0 && pt_ok) a.iters[pidx * (a.max_level + 1) + level] = it_count;
+        if (a.iters && hl == 0 && pt_ok) a.iters[pidx * (a.max_level + 1) + level] = it_count | ((a.flags & DR3HIP_LK_DIAG_RESTAGES) ? restages << 16 : 0);
 
         // ---- residual (level 0 only) -----------------------------------------------------------------
         if (level == 0 && !(a.flags & DR3HIP_LK_GET_MIN_EIGENVALS)) {

@@ -496,8 +496,11 @@ def main(argv=None):
         batch.track(B, 0, d_prev, d_next, N_PTS, d_st, d_err, params, d_iters=d_it); sync()
         it = d_it.download((B, N_PTS, levels), np.int32).sum(2)
         ppw = int(lk_kernel_of(WIN, WIN).split(",")[1])
+        itl = d_it.download((B, N_PTS, levels), np.int32)[:, :N_PTS // ppw * ppw].reshape(B, -1, ppw, levels)
         lk_iters = {"mean_iteration_levels_per_point": float(it.mean()), "points_per_wave": ppw,
-                    "mean_iteration_levels_of_slowest_in_group": float(it[:, :N_PTS // ppw * ppw].reshape(B, -1, ppw).max(2).mean())}
+                    "mean_iteration_levels_of_slowest_in_group": float(it[:, :N_PTS // ppw * ppw].reshape(B, -1, ppw).max(2).mean()),
+                    "executed_iteration_levels_per_wave": float(itl.max(2).sum(2).mean()),
+                    "executed_note": "what a wave executes: sum over levels of the slowest point of its lock-step group on that level"}
         d_it.free()
 
     # ---- what this box's HBM delivers on a plain device-to-device copy (report beside the nominal 8 TB/s)
@@ -573,6 +576,11 @@ def main(argv=None):
     if args.workload == "kitti" and not args.no_host_api and have_gpu:
         rx = d_next.download((B, N_PTS, 2), np.float32); rs = d_st.download((B, N_PTS), np.uint8)
         stream = stream_leg(dist, ctx, dr3, frames, P, B, N_PTS, (W, H), params, sync, max(6, min(args.steps, 20)), rx, rs, have_gpu)
+
+    # ---- configs[4], one GPU's share, bounded (64 pairs, 5 timed steps): the driver's default line carries it ---------------------
+    hd_share = None
+    if args.workload == "kitti" and not args.no_frontend and have_gpu:
+        hd_share = hd_share_leg(dist, ctx, dr3, synth, sync)
 
     # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------
     warp = None
@@ -668,6 +676,7 @@ def main(argv=None):
             "frontend": frontend,
             "lk_other_windows": lk_other,
             "lk_real_frames": lk_real,
+            "hd_share": hd_share,
             "post_lk_geometry": post_lk,
             "two_streams": two_streams,
             "sparse_align": align,
@@ -688,6 +697,70 @@ def main(argv=None):
     ctx.close()
     dist.close()
     return 0
+
+
+def hd_share_leg(dist, ctx, dr3, synth, sync, steps=5, pairs=64):
+    """BASELINE configs[4], one GPU's share, bounded so that the driver's default run carries it: `pairs` 1920x1080 frame pairs per step
+    (5000 corners, 5-level pyramid, 21x21 window, 30 iterations), `steps` timed steps of pyramid + gradient pass and tracker, inputs
+    resident; the level-0 kernel against the HBM roofline with the committed PMC traffic of this launch shape; pair 0 against the oracle
+    in the kernel's order (bit for bit) and in OpenCV's two (x86-64 SIMD and scalar).  `python bench.py --workload hd` is the long form."""
+    W_, H_, NPTS, WIN_, ML = 1920, 1080, 5000, 21, 4
+    frames, _ = stream_frames(synth, pairs + 1, W_, H_, period=3)
+    b = dr3.FrameBatch(ctx, W_, H_, win=(WIN_, WIN_), max_level=ML, capacity=pairs + 1)
+    for s0 in range(0, pairs + 1, 16):
+        b.upload(s0, np.stack(frames[s0:s0 + 16]))
+    pts = synth.grid_points(W_, H_, 20, n=NPTS)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (pairs, NPTS, 2)), np.float32)
+    d_prev, d_next = ctx.to_device(P), ctx.to_device(P)
+    d_st, d_err = ctx.alloc(pairs * NPTS), ctx.alloc(pairs * NPTS * 4)
+    kw = dict(win=(WIN_, WIN_), max_level=ML, max_iters=MAX_ITERS, eps=EPS, flags=0)
+    params = dr3.lk_params(**kw)
+    b.build(0, pairs + 1, True)
+
+    def step():
+        b.build(1, pairs, True)
+        b.track(pairs, 0, d_prev, d_next, NPTS, d_st, d_err, params)
+
+    for _ in range(8):
+        step()
+    sync()
+    ctx.profile_enable(True); ctx.profile_reset()
+    el = timed_region(dist, step, sync, steps, 0)
+    ms_l0, n_l0 = ctx.profile_read(dr3.PROF_PYR_L0)
+    ms_pass, n_pass = ctx.profile_read(dr3.PROF_PYR)
+    ms_lk, n_lk = ctx.profile_read(dr3.PROF_LK)
+    ctx.profile_enable(False)
+    l0_ms, pass_ms, lk_ms = ms_l0 / max(n_l0, 1), ms_pass / max(n_pass, 1), ms_lk / max(n_lk, 1)
+    b_l0 = pyr_grad_level0_bytes_per_frame(W_, H_) * pairs
+    b_pass = pyr_grad_bytes_per_frame(W_, H_, b.levels) * pairs
+    traffic, tsrc = pmc_traffic("pyr_level_kernel<true, true, 0>", pairs, "pmc_traffic_hd.json")
+    verified, orders = None, None
+    if dist.rank == 0:
+        from oracle import oracle as O
+        po = O.lk_params(**kw)
+        g_xy = d_next.download((pairs, NPTS, 2), np.float32)[0]; g_st = d_st.download((pairs, NPTS), np.uint8)[0]
+        res = {o: O.lk_track(frames[0], frames[1], pts, None, po, order=o, want_iters=True, opt=True) for o in (O.ORDER_WAVE64, O.ORDER_SSE2, O.ORDER_RASTER)}
+        k = res[O.ORDER_WAVE64]
+        verified = bool(np.array_equal(g_xy.view(np.uint32), k[0].view(np.uint32)) and np.array_equal(g_st, k[1]))
+        g = (g_xy, g_st, None, k[3], k[4])
+        orders = {"kernel_vs_sse2": O.order_agreement(g, res[O.ORDER_SSE2], po, 1e-3), "kernel_vs_raster": O.order_agreement(g, res[O.ORDER_RASTER], po, 1e-3),
+                  "raster_vs_sse2": O.order_agreement(res[O.ORDER_RASTER], res[O.ORDER_SSE2], po, 1e-3)}
+    out = {"workload": "configs[4], one GPU's share, bounded: %d pairs 1920x1080 per step, %d corners, %d-level pyramid, %dx%d window, %d timed steps"
+                       % (pairs, NPTS, b.levels, WIN_, WIN_, steps),
+           "keypoints_per_sec": aggregate_rate(dist, pairs * NPTS * steps, el), "ms_per_step": el / steps * 1e3,
+           "roofline": {"kernel": "pyr_level_kernel<DOWN,DERIV,0> (fused pyrDown+Scharr, level 0)", "bound": "hbm",
+                        "achieved": b_l0 / (l0_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_l0 / (l0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "traffic": traffic, "traffic_source": tsrc,
+                        "frac_moved": None if not traffic else traffic / (l0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_launch": b_l0, "avg_launch_ms": l0_ms, "launches": n_l0},
+           "pyr_grad_pass": {"avg_pass_ms": pass_ms, "frac": b_pass / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_pass": b_pass},
+           "lk_kernel": {"kernel": lk_kernel_of(WIN_, WIN_), "avg_launch_ms": lk_ms, "keypoints_per_sec_kernel_only": pairs * NPTS / (lk_ms * 1e-3)},
+           "tracked_fraction": float(d_st.download((pairs, NPTS), np.uint8).mean()),
+           "verified_vs_oracle": verified, "summation_order_agreement": orders}
+    for d in (d_prev, d_next, d_st, d_err):
+        d.free()
+    b.close()
+    return out
 
 
 def frontend_leg(dist, ctx, dr3, batch, B, sync, steps):
@@ -1059,7 +1132,8 @@ def lk_real_pair_leg(dist, ctx, dr3, sync, have_gpu):
         ms, cnt = ctx.profile_read(dr3.PROF_LK)
         ctx.profile_enable(False)
         d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params, d_iters=d_it); sync()      # untimed: with the iteration counts
-        it = d_it.download((NP, n, lv), np.int32).sum(2)                                                    # iteration-levels per point slot
+        itl_ = d_it.download((NP, n, lv), np.int32)
+        it = itl_.sum(2)                                                                                    # iteration-levels per point slot
         ppw = int(lk_kernel_of(*kw["win"]).split(",")[1])
         vm = (P[:, :, 0] > -1.0e5)
         grp = it[:, :n // ppw * ppw].reshape(NP, -1, ppw)
@@ -1076,6 +1150,7 @@ def lk_real_pair_leg(dist, ctx, dr3, sync, have_gpu):
                      "keypoints_per_sec_kernel_only": valid / (k_ms * 1e-3), "tracked_fraction_of_valid": float(g_st[vm].mean()),
                      "mean_iteration_levels_per_point": float(it[vm].mean()), "points_per_wave": ppw,
                      "mean_iteration_levels_of_slowest_in_group": float(grp.max(2)[grp_live].mean()),
+                     "executed_iteration_levels_per_wave": float(itl_[:, :n // ppw * ppw].reshape(NP, -1, ppw, lv).max(2).sum(2)[grp_live].mean()),
                      "points_at_the_iteration_clamp_frac": float((d_it.download((NP, n, lv), np.int32).max(2)[vm] >= min(kw["max_iters"], 100)).mean()),
                      "verified_vs_oracle": ok}
         for d in (d_prev, d_next, d_st, d_err, d_it):

@@ -44,6 +44,8 @@ extern "C" {
 /* flags */
 #define DR3HIP_LK_USE_INITIAL_FLOW    4   /* == cv::OPTFLOW_USE_INITIAL_FLOW (src/initialization.cpp:613) */
 #define DR3HIP_LK_GET_MIN_EIGENVALS   8   /* == cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+#define DR3HIP_LK_DIAG_RESTAGES (1 << 20) /* diagnostic (no OpenCV counterpart, results unchanged): the iteration counts written to d_iters carry, in bits 16..31,
+                                           * how often an iterate left the staged search region of its level and the region was fetched again */
 #define DR3HIP_WARP_INVERSE_MAP      16   /* == cv::WARP_INVERSE_MAP */
 #define DR3HIP_CRIT_COUNT             1   /* == cv::TermCriteria::COUNT */
 #define DR3HIP_CRIT_EPS               2   /* == cv::TermCriteria::EPS   */

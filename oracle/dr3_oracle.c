@@ -257,6 +257,11 @@ static float wsum_get(wsum* s, int which)
 }
 
 
+/* debug sink (tools only, single-threaded callers): the iterate (cx, cy) -- window origin, before the step -- of every Gauss-Newton
+ * iteration of the point being tracked: traj[(level * 101 + j) * 2 + {0,1}], j = 0 is the level's starting estimate */
+static float* g_traj = NULL;
+void dr3o_debug_set_traj(float* buf) { g_traj = buf; }
+
 static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* dI,
                            int max_level, const float* prev_pt, float* next_pt,
                            uint8_t* status, float* err,
@@ -358,6 +363,7 @@ static void lk_track_point(const lvl_img* I, const lvl_img* J, const lvl_deriv* 
                 break;
             }
             if (iters) iters[level] = j + 1;
+            if (g_traj) { g_traj[(level * 101 + j) * 2] = cx; g_traj[(level * 101 + j) * 2 + 1] = cy; }
 
             a = cx - inx; b = cy - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));

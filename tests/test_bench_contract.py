@@ -49,7 +49,18 @@ def test_contract_fields_and_arithmetic():
         assert vi["frac"] == pytest.approx(vi["achieved"] / vi["peak"], rel=1e-9) and 2.0 <= vi["avg_issue_clocks_per_valu"] <= 8.0
         assert vi["peak"] == pytest.approx(1024 * 2.4 / vi["avg_issue_clocks_per_valu"], rel=1e-9)
     # every leg that ran carries its check against the oracle
-    assert d["raster_order_agreement"]["same_path_within_tol"] is True and 0.99 <= d["raster_within_1e-3_frac"] <= 1.0
+    assert d["raster_order_agreement"]["same_path_max_dev_px"] <= 1.25e-3 and 0.99 <= d["raster_within_1e-3_frac"] <= 1.0
+    if os.path.basename(os.path.dirname(path)) >= "r04":
+        # north_star's 1e-3 px bar against the order the reference's x86-64 OpenCV executes, on the metric's configuration AND on
+        # configs[4]'s pair (the one round 3 found over the bar against the scalar order): every converged point, no exception list
+        assert d["pre_roll_steps"] == 256
+        for rec in (d["summation_order_agreement"], d["hd_share"]["summation_order_agreement"]):
+            ks = rec["kernel_vs_sse2"]
+            assert ks["status_equal"] and ks["same_path_within_tol"] and ks["converged_within_tol"], ks
+            assert ks["tracked_both"] - ks["clamped"] >= 0.99 * ks["tracked_both"]
+        assert d["hd_share"]["verified_vs_oracle"] is True and 0 < d["hd_share"]["roofline"]["frac"] <= 1.0
+        assert d["cpu_baseline"]["port_opt_equals_port_bit_for_bit"] is True
+        assert d["cpu_baseline"]["value"] >= d["cpu_baseline"]["readable_port"]["value"]       # the >= 50x target is quoted against the faster port
     for leg in ("8uc3", "32fc4", "kitti_frames_8uc3", "paste", "stitch"):
         assert d["warp"][leg]["verified_vs_oracle"] is True, leg
     for leg in d["lk_other_windows"].values():
