@@ -180,6 +180,7 @@ def _signatures():
         "dr3hip_stitch_geometry": ([vp, ip, ip, vp, vp, vp, P(ip), P(ip)], ip),
         "dr3hip_stitch_compose": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
         "dr3hip_stitch_compose_dev": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
+        "dr3hip_stitch_plan": ([vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, P(ip)], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
         "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
@@ -719,6 +720,20 @@ def panorama_ramp(min_x, max_x, feathering_width):
     if n < 0:
         raise Dr3HipError("dr3hip_panorama_ramp: the reference throws for this box (%d)" % n)
     return ramp[:n]
+
+
+def stitch_plan(lw, lh, rw, rh, T, M, size, alpha=0.5, beta=0.5, gamma=0.0, lstride=None, rstride=None):
+    """which form a fused stitch of these images takes (dr3hip_stitch_plan): 2 = strips, 0 = direct; strides default to the 64-byte
+    aligned pitches the host-buffer entry point stages with"""
+    k = C.c_int()
+    ls = lstride if lstride is not None else (3 * lw + 63) // 64 * 64
+    rs = rstride if rstride is not None else (3 * rw + 63) // 64 * 64
+    rc = lib().dr3hip_stitch_plan(None, lw, lh, ls, None, rw, rh, rs, _p(np.ascontiguousarray(np.asarray(T, np.float32).reshape(9))),
+                                  _p(np.ascontiguousarray(np.asarray(M, np.float32).reshape(9))), int(size[0]), int(size[1]),
+                                  C.c_float(alpha), C.c_float(beta), C.c_float(gamma), C.byref(k))
+    if rc != 0:
+        raise Dr3HipError("dr3hip_stitch_plan failed: %d" % rc)
+    return k.value
 
 
 def stitch_geometry(H, w, h):

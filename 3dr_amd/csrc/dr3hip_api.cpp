@@ -778,6 +778,19 @@ int dr3hip_stitch_geometry(const float H[9], int w, int h, float Hinv[9], float 
     return DR3HIP_OK;
 }
 
+int dr3hip_stitch_plan(const uint8_t* d_left, int lw, int lh, int lstride, const uint8_t* d_right, int rw, int rh, int rstride,
+                       const float T[9], const float M_right[9], int new_w, int new_h, float alpha, float beta, float gamma, int* kernel)
+{
+    if (!T || !M_right || !kernel || lw < 1 || lh < 1 || rw < 1 || rh < 1 || new_w < 1 || new_h < 1) return DR3HIP_EINVAL;
+    StitchArgs a;
+    make_job(a.job[0], d_left, lw, lh, lstride, nullptr, new_w, new_h, 3 * new_w, T, 0);
+    make_job(a.job[1], d_right, rw, rh, rstride, nullptr, new_w, new_h, 3 * new_w, M_right, 0);
+    a.dst = nullptr; a.dw = new_w; a.dh = new_h; a.dstride = 3 * new_w;
+    a.alpha = alpha; a.beta = beta; a.gamma = gamma;
+    *kernel = stitch_takes_strips(a) ? 2 : 0;
+    return DR3HIP_OK;
+}
+
 int dr3hip_stitch_compose_dev(dr3hip_ctx* ctx, const uint8_t* d_left, int lw, int lh, int lstride,
                               const uint8_t* d_right, int rw, int rh, int rstride,
                               const float T[9], const float M_right[9], int new_w, int new_h,

@@ -205,6 +205,7 @@ hipError_t launch_fast_level(const FastArgs& a, hipStream_t s);     // score (ma
 hipError_t launch_cells_decode(const CellsArgs& a, hipStream_t s);
 hipError_t launch_normalize_points(const NormArgs& a, hipStream_t s);
 hipError_t launch_sparse_align(const AlignArgs& a, int n_pairs, hipStream_t s);
+bool stitch_takes_strips(const StitchArgs& a);      // host only: would launch_stitch_compose run the strip form on these records?
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);

@@ -608,19 +608,94 @@ __device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M
     return __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);
 }
 
-// Every job of the launch: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
-// (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
-__global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* __restrict__ jobs, int tiles_x, int n_tiles, int lds_bytes, int run)
+// cv::addWeighted for 8-bit data: saturate(cvRound(l * alpha + r * beta + gamma)) in f32
+__device__ __forceinline__ uint32_t add_weighted_u8(uint32_t l, uint32_t r, float alpha, float beta, float gamma)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const WarpJobDev& jb = jobs[blockIdx.y];
-    // block -> tile: linear block ids b, b + 8 share an XCD (and its L2); an XCD takes `run` x-adjacent tiles in a row, so that the
-    // source boxes and the 192-byte row segments of neighbouring tiles meet in one L2 (run = 4 on wide destinations: 1.15 instead of
-    // 1.38 times the algorithmic bytes on the 4000 x 3000 tiles at the same speed; run = 1, raster order, on narrow ones: the
-    // 1241 x 376 frames are 10 % faster that way -- profiles/r03_warp/README.md).  `run` is a power of two, the grid a multiple of 8 run.
-    const int b = blockIdx.x, r = b & (8 * run - 1);
-    const int t = (b - r) + (r & 7) * run + (r / 8);
-    if (t >= n_tiles) return;
+    const float t = (float)l * alpha + (float)r * beta + gamma;
+    const int v = __float2int_rn(t);
+    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+// ---- the left image of a fused stitch (reference src/stitch.cpp:74: warpPerspective(left, translate_top_left)) -----------------------
+// A pure translation: OpenCV's coordinates are X = rint(32 x + 32 tx) = 32 x + Kx for every pixel (the f64 products and sums are exact
+// and 32 x is even, so round-half-even decides every pixel alike), i.e. ONE tap offset (ix, iy) = (Kx >> 5, Ky >> 5) and ONE pair of
+// fractions (Kx & 31, Ky & 31) for the whole canvas.  In the strip form of the fused stitch a lane reads the two taps of a row of its
+// column as ONE aligned 12-byte load (the 64 lanes of a wave read 200 contiguous bytes: no LDS), blends with constant weights, and the horizontal sums of a row serve the pixel above and the one below (the integers
+// distribute exactly, see Blend8).  Strips that touch the image's border take per-tap checked loads instead (4 % of a 4000 x 3000 image).
+struct StitchLeft {
+    const uint8_t* src; int sw, sh, sstride;   // rows 16-byte aligned
+    int ix, iy;                                // tap of canvas pixel (x, y): (x + ix, y + iy)
+    uint32_t wlo, whi, wy0, wy1;               // Blend8 of the constant fractions
+    int fx, fy;                                // the fractions themselves (strips on the image border take checked taps)
+    int avg;                                   // alpha == beta == 0.5, gamma == 0 (the reference's literals): the v_lerp_u8 form
+    float alpha, beta, gamma;
+};
+
+// cv::addWeighted on [B G R 0] dwords.  avg: l * 0.5f + r * 0.5f + 0.f is exact in f32, so cvRound gives (l + r) / 2 rounded half to even:
+// floor((l + r) / 2) per byte (v_lerp_u8) plus its own low bit where l + r is odd.
+__device__ __forceinline__ uint32_t stitch_blend_px(uint32_t l, uint32_t r, const StitchLeft& sl)
+{
+    if (sl.avg) {
+        const uint32_t f = __builtin_amdgcn_lerp(l, r, 0u);
+        return f + (((l ^ r) & 0x01010101u) & f);
+    }
+    const uint32_t b = add_weighted_u8(l & 255u, r & 255u, sl.alpha, sl.beta, sl.gamma);
+    const uint32_t g = add_weighted_u8((l >> 8) & 255u, (r >> 8) & 255u, sl.alpha, sl.beta, sl.gamma);
+    const uint32_t c = add_weighted_u8((l >> 16) & 255u, (r >> 16) & 255u, sl.alpha, sl.beta, sl.gamma);
+    return b | (g << 8) | (c << 16);
+}
+
+// horizontal sums (B, G, R) of the two taps [B0 G0 R0 B1 G1 R1] of one row: 12 bytes from the dword-aligned address p below the taps
+// (ONE aligned global_load_dwordx3: the 64 lanes of a wave read 200 contiguous bytes; an unaligned 8-byte load per lane measured 28 %
+// slower than staging the box through LDS), shifted into place by the lane's byte offset sh = taps' address & 3
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3 left_row_load(gcu8 p) { return *reinterpret_cast<const DR3_G u32x3*>(p); }
+__device__ __forceinline__ void left_row_sums(const u32x3 v, uint32_t sh, const Blend8& w, uint32_t& hb, uint32_t& hg, uint32_t& hr)
+{
+    const uint32_t lo = __builtin_amdgcn_alignbyte(v.y, v.x, sh), hi = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+    blend8_row2(__builtin_amdgcn_perm(hi, lo, 0x04010300u), w, hb, hg);                                      // [B0 B1 G0 G1]
+    hr = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(hi, lo, 0x0c0c0502u), w.wlo, DR3_HROUND, false);       // [R0 R1 0 0]
+}
+__device__ __forceinline__ uint32_t left_px(uint32_t hb0, uint32_t hg0, uint32_t hr0, uint32_t hb1, uint32_t hg1, uint32_t hr1, const Blend8& w)
+{
+    const uint32_t aB = blend8_vert(hb0, hb1, w), aG = blend8_vert(hg0, hg1, w), aR = blend8_vert(hr0, hr1, w);
+    return __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);             // [B G R 0]
+}
+
+// One canvas column of 16 rows of a fused stitch by OpenCV's own sequences and per-tap checked loads (the strip form's way out)
+__device__ __forceinline__ void stitch_fallback_8uc3(const WarpJobDev& jr, const WarpJobDev& jl, const StitchLeft& sl, int x, int y0)
+{
+    if (x >= jr.dw) return;
+    gu8 dst = (gu8)jr.dst;
+    for (int j = 0; j < kWaveRows; ++j) {
+        const int y = y0 + j;
+        if (y >= jr.dh) return;
+        uint32_t px[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const WarpJobDev& jb = s ? jr : jl;
+            double M[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
+            const int x0 = block_origin(x, jb.bw0, jb.bw0_shift);
+            const Tap t = persp_tap(M, persp_base(M, x0, y), (double)(x - x0));
+            uint32_t aB = 0u, aG = 0u, aR = 0u;
+            pixel_8uc3((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, false, t, aB, aG, aR);
+            px[s] = byte2(aB) | (byte2(aG) << 8) | (byte2(aR) << 16);
+        }
+        const uint32_t v = stitch_blend_px(px[0], px[1], sl);
+        gu8 o = dst + (long long)y * jr.dstride + (long long)x * 3;
+        o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
+    }
+}
+
+// One 64 x 64 tile (four strips, one per wave) of one job.  STITCH: jb is the RIGHT image's job of a fused stitch, jl the left image's
+// (exact fallback), sl its translation form: the strip's pixels are addWeighted(left, right) instead of the warped right image.
+// Every job: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
+// (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
+template <bool STITCH>
+__device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const WarpJobDev* jl, const StitchLeft* slp, int t, int tiles_x, int lds_bytes, uint8_t* s_dyn)
+{
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tx0 = tx * kTileW, ty0 = ty * kTileH;
     const int dw = jb.dw, dh = jb.dh;
@@ -637,7 +712,7 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
     const bool dst_aligned = ((reinterpret_cast<uintptr_t>(jb.dst) | (uintptr_t)dstride) & 3) == 0;
     const bool src16 = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)sstride) & 15) == 0 &&
                        sstride < (1 << 24) && sh < (1 << 24) && (long long)sstride * sh < (1LL << 31);
-    if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { tile_fallback_8uc3(jb, x, y0); return; }
+    if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else tile_fallback_8uc3(jb, x, y0); return; }
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_dyn + (uint32_t)wv * (uint32_t)(lds_bytes + 256);    // this wave's slice (LDS byte address)
     const uint32_t list0 = lds0 + (uint32_t)lds_bytes;
 
@@ -688,10 +763,33 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
         g.pitch = g.cpr * 16;
     }
     if (!(g.cpr >= 1 && g.cpr <= 64 && g.rows >= 1 && g.rows <= 4096 && g.rows * g.pitch <= lds_bytes && g.ox > -16384 && g.oy > -16384)) {
-        tile_fallback_8uc3(jb, x, y0); return;
+        if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else tile_fallback_8uc3(jb, x, y0);
+        return;
     }
-    if (g.ox >= 0 && g.ox + 4 * g.cpr <= sw && g.oy >= 0 && g.oy + g.rows <= sh) stage_strip_bgrx<false>(g, src, sw, sh, sstride, lds0, lane);
-    else                                                                          stage_strip_bgrx<true>(g, src, sw, sh, sstride, lds0, lane);
+    // a box that lies outside the image by more than the pixel a rounding tie can move a tap: every pixel of the strip is the border
+    // constant -- nothing is staged, no coordinate is evaluated (the canvas of a stitch is mostly such strips for one image or the other)
+    const bool r_any = !(g.ox - 2 >= sw || g.ox + 4 * g.cpr + 2 <= 0 || g.oy - 2 >= sh || g.oy + g.rows + 2 <= 0);
+    if (r_any) {
+        if (g.ox >= 0 && g.ox + 4 * g.cpr <= sw && g.oy >= 0 && g.oy + g.rows <= sh) stage_strip_bgrx<false>(g, src, sw, sh, sstride, lds0, lane);
+        else                                                                          stage_strip_bgrx<true>(g, src, sw, sh, sstride, lds0, lane);
+    }
+    // STITCH: the left image under this strip: columns tx0 + ix .. + 65, rows y0 + iy .. + n_rows.  lmode 0: none of it inside the image;
+    // 1: all of it (and the two bytes an 8-byte tap load reads beyond the right tap) inside: direct loads; 2: on the border: checked taps
+    int lmode = 0;
+    gcu8 lrow = nullptr;                                                    // dword below the lane's taps of the strip's first row
+    uint32_t lsh = 0u;
+    Blend8 wl; wl.wlo = wl.whi = wl.wy0 = wl.wy1 = 0u;
+    if (STITCH) {
+        const StitchLeft& sl = *slp;
+        wl.wlo = sl.wlo; wl.whi = sl.whi; wl.wy0 = sl.wy0; wl.wy1 = sl.wy1;
+        const int lx0 = tx0 + sl.ix, ly0 = y0 + sl.iy;
+        const bool any = !(lx0 >= sl.sw || lx0 + kTileW + 1 <= 0 || ly0 >= sl.sh || ly0 + n_rows + 1 <= 0);
+        const bool inside = lx0 >= 0 && lx0 + kTileW + 4 <= sl.sw && ly0 >= 0 && ly0 + n_rows + 1 <= sl.sh;      // + 4: the 12-byte load's reach
+        lmode = !any ? 0 : inside ? 1 : 2;
+        const long long lb = 3ll * (lx0 + lane);
+        lsh = (uint32_t)lb & 3u;                                            // rows are 16-byte aligned: the same byte offset on every row
+        lrow = (gcu8)sl.src + ((long long)ly0 * sl.sstride + (lb & ~3ll));
+    }
     __builtin_amdgcn_wave_barrier();                            // a wave's LDS operations complete in order: no s_barrier
     const uint32_t pitch = (uint32_t)g.pitch;
     // region-relative: bits 18.. of aX / aY are the LDS column / row
@@ -708,12 +806,29 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
     gu8 obase = dst + (long long)y0 * dstride + (long long)tx0 * 3;         // wave-uniform
     uint32_t own = 0u;                                                      // ties of this lane's column that the list had no room for
     int n_list = 0;                                                         // wave-uniform
+    uint32_t lhb = 0u, lhg = 0u, lhr = 0u;                                  // STITCH: horizontal sums of the left image's row above the next pixel row
+    // the left image's rows are fetched one group of four pixel rows ahead of their use (a load issued where it is used leaves the
+    // wave waiting for memory once per row: the direct form's speed)
+    u32x3 lv[4] = {};
+    if (STITCH && lmode == 1) {
+        left_row_sums(left_row_load(lrow), lsh, wl, lhb, lhg, lhr);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lv[u] = left_row_load(lrow + (long long)min(u + 1, n_rows) * slp->sstride);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j0 = 0; j0 < kWaveRows; j0 += 4) {
         if (j0 >= n_rows) break;
         uint32_t nearest = 0xffffffffu;
         int aX[4], aY[4];
-        uint32_t P[4];
+        uint32_t P[4] = {0u, 0u, 0u, 0u};
+        u32x3 ln[4] = {};
+        if (STITCH && lmode == 1 && j0 + 4 < n_rows) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ln[u] = left_row_load(lrow + (long long)min(j0 + 5 + u, n_rows) * slp->sstride);
+            __builtin_amdgcn_sched_barrier(0);           // the scheduler would sink the loads to their uses, a group later
+        }
+        if (r_any) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float oj = (float)(j0 + u) - 7.5f;
@@ -734,7 +849,28 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
             blend_taps_bgrx(tl, tr, bl, br, w, aB, aG, aR);
             P[u] = __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);           // [B G R 0]
         }
-        if (__builtin_amdgcn_ballot_w64(nearest < g2)) {                                                                   // rare: note the pixels on a tie in the wave's list
+        }
+        if (STITCH) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t Lp = 0u;
+                if (lmode == 1 && j0 + u < n_rows) {             // wave-uniform
+                    uint32_t nb_, ng_, nr_;
+                    left_row_sums(lv[u], lsh, wl, nb_, ng_, nr_);
+                    Lp = left_px(lhb, lhg, lhr, nb_, ng_, nr_, wl);
+                    lhb = nb_; lhg = ng_; lhr = nr_;
+                } else if (lmode == 2 && j0 + u < n_rows) {
+                    Tap tl_; tl_.sx = x + slp->ix; tl_.sy = y0 + j0 + u + slp->iy; tl_.fx = slp->fx; tl_.fy = slp->fy;
+                    uint32_t aB = 0u, aG = 0u, aR = 0u;
+                    pixel_8uc3((gcu8)slp->src, slp->sw, slp->sh, slp->sstride, false, tl_, aB, aG, aR);
+                    Lp = __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);
+                }
+                P[u] = stitch_blend_px(Lp, P[u], *slp);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lv[u] = ln[u];
+        }
+        if (r_any && __builtin_amdgcn_ballot_w64(nearest < g2)) {                                                                   // rare: note the pixels on a tie in the wave's list
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool tie = (min((uint32_t)aX[u] & 8191u, (uint32_t)aY[u] & 8191u) < g2) && x < dw && j0 + u < n_rows;
@@ -771,10 +907,60 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
         if (i < n_list) { const uint32_t e = *(lds_u32)(uintptr_t)(list0 + 4u * (uint32_t)i); xe = tx0 + (int)(e & 255u); ye = y0 + (int)(e >> 8); i += 64; }
         else if (own) { xe = x; ye = y0 + __builtin_ctz(own); own &= own - 1u; }
         else break;
-        const uint32_t v = tile_redo_pixel(M, bw0_shift, g, lds0, src, sw, sh, sstride, xe, ye);
+        uint32_t v = tile_redo_pixel(M, bw0_shift, g, lds0, src, sw, sh, sstride, xe, ye);
+        if (STITCH) {
+            uint32_t Lp = 0u;
+            if (lmode) {
+                Tap tl_; tl_.sx = xe + slp->ix; tl_.sy = ye + slp->iy; tl_.fx = slp->fx; tl_.fy = slp->fy;
+                uint32_t aB = 0u, aG = 0u, aR = 0u;
+                pixel_8uc3((gcu8)slp->src, slp->sw, slp->sh, slp->sstride, false, tl_, aB, aG, aR);
+                Lp = __builtin_amdgcn_perm(aR, __builtin_amdgcn_perm(aG, aB, 0x0c0c0602u), 0x0c060100u);
+            }
+            v = stitch_blend_px(Lp, v, *slp);
+        }
         gu8 o = dst + (long long)ye * dstride + (long long)xe * 3;
         o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
     }
+}
+
+
+__global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* __restrict__ jobs, int tiles_x, int n_tiles, int lds_bytes, int run, int n_jobs_arg)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    // block -> (job, tile): linear block ids b, b + 8 share an XCD (and its L2).
+    // run > 0: an XCD takes `run` x-adjacent tiles in a row, so that the source boxes and the 192-byte row segments of neighbouring tiles
+    // meet in one L2 (run = 4 on wide destinations: 1.15 instead of 1.38 times the algorithmic bytes on the 4000 x 3000 tiles at the same
+    // speed; run = 1, raster order: profiles/r03_warp/README.md).  `run` is a power of two, the grid a multiple of 8 run.
+    // run == 0 (many jobs with small destinations, e.g. 256 frames of 1241 x 376): a JOB per XCD -- XCD k walks the jobs k, k + 8, ...
+    // tile by tile, so every source row a job's strips share is fetched into ONE L2 once (raster order dealt the tiles of a frame over all
+    // eight L2s: 1.37 times the algorithmic bytes).  The grid is one-dimensional then: 8-aligned jobs x n_tiles blocks, the rest behind.
+    int job, t;
+    if (run == 0) {
+        const unsigned b = blockIdx.x, n_jobs = (unsigned)n_jobs_arg, full = (n_jobs & ~7u) * (unsigned)n_tiles;
+        if (b < full) { const unsigned k = b >> 3, g = k / (unsigned)n_tiles; t = (int)(k - g * (unsigned)n_tiles); job = (int)(g * 8u + (b & 7u)); }
+        else          { const unsigned r = b - full, g = r / (unsigned)n_tiles; t = (int)(r - g * (unsigned)n_tiles); job = (int)((n_jobs & ~7u) + g); }
+        if (job >= (int)n_jobs) return;
+    } else {
+        const int b = blockIdx.x, r = b & (8 * run - 1);
+        t = (b - r) + (r & 7) * run + (r / 8);
+        job = blockIdx.y;
+    }
+    const WarpJobDev& jb = jobs[job];
+    if (t >= n_tiles) return;
+    strip_tile_body<false>(jb, nullptr, nullptr, t, tiles_x, lds_bytes, s_dyn);
+}
+
+// the fused stitch on strips: a.job[1] (right image) through the strip machinery, a.job[0] (left image) in its translation form sl
+// (the records are kernel arguments: everything that takes them is inlined, so they stay in the kernarg segment and are read with scalar
+// loads -- a noinline callee would make every wave copy them to scratch, and a copy to device memory per call costs more than the kernel)
+struct StitchDev { StitchArgs a; StitchLeft sl; };
+__global__ __launch_bounds__(256) void stitch_strip_kernel(const StitchDev sd, int tiles_x, int n_tiles, int lds_bytes, int run)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const int b = blockIdx.x, r = b & (8 * run - 1);
+    const int t = (b - r) + (r & 7) * run + (r / 8);
+    if (t >= n_tiles) return;
+    strip_tile_body<true>(sd.a.job[1], &sd.a.job[0], &sd.sl, t, tiles_x, lds_bytes, s_dyn);
 }
 
 // MAPS = 0: (u, v) read from two f32 planes (cv::remap, reference src/utils.cpp:191).
@@ -868,12 +1054,6 @@ __global__ __launch_bounds__(256) void remap_kernel(const RemapArgs a)
 // 6 r + 3 w bytes per pixel) as one: a lane owns 4 adjacent output pixels, samples both sources with the 8UC3 machinery
 // above (each with its own job record: inverse map, block split, fast-coordinate flag) and blends
 // saturate(cvRound(l * alpha + r * beta + gamma)) in f32 as cv::addWeighted does for 8-bit data.
-__device__ __forceinline__ uint32_t add_weighted_u8(uint32_t l, uint32_t r, float alpha, float beta, float gamma)
-{
-    const float t = (float)l * alpha + (float)r * beta + gamma;
-    const int v = __float2int_rn(t);
-    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-}
 
 template <bool GENERIC>
 __global__ __launch_bounds__(256) void stitch_compose_kernel(const StitchArgs a)
@@ -1117,13 +1297,19 @@ hipError_t launch_warp(const WarpJobDev* d_jobs, int n_jobs, int max_dw, int max
         const int tiles_x = (max_dw + kTileW - 1) / kTileW;
         const long long n_tiles = (long long)tiles_x * ((max_dh + kTileH - 1) / kTileH);
         if (n_tiles < (1LL << 30)) {
-            const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
-            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp), n_jobs, 1);
+            // many jobs of small destinations: a job per XCD (run 0; the job count rides in the kernel's n_jobs argument, the grid is linear)
+#ifdef DR3_WARP_NO_PER_XCD
+            const bool per_xcd = false;                                        // experiment builds: the tile-per-XCD order of round 3
+#else
+            const bool per_xcd = n_jobs >= 16 && n_tiles <= 1024 && n_tiles * (long long)n_jobs < (1LL << 30);
+#endif
+            const int run = per_xcd ? 0 : tiles_x >= 32 ? 4 : 1, grp = 8 * (run ? run : 1);
+            dim3 tgrid(per_xcd ? (unsigned)(n_tiles * n_jobs) : (unsigned)((n_tiles + grp - 1) / grp * grp), per_xcd ? 1 : n_jobs, 1);
             int lds = (std::max(tile_lds, 1024) + 255) & ~255;               // a wave's slice; behind it the wave's tie list (256 B)
 #ifdef DR3_WARP_EXPERIMENT
             if (const char* e = getenv("DR3HIP_TILE_LDS")) lds = std::min((std::max(atoi(e), 1024) + 255) & ~255, kWarpTileLdsBytes);      // slice-size sweeps: experiment builds only
 #endif
-            hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds, run);
+            hipLaunchKernelGGL(warp_tile_8uc3_kernel, tgrid, block, 4 * (lds + 256), s, d_jobs, tiles_x, (int)n_tiles, lds, run, n_jobs);
             return hipGetLastError();
         }
     }
@@ -1162,10 +1348,54 @@ hipError_t launch_remap(const RemapArgs& a, int type, hipStream_t s)
     return hipGetLastError();
 }
 
+// The strip form of the fused stitch (stitch_strip_kernel): the right image's job runs on the strip kernel (WarpJobDev::tile == 2), the
+// left image's map is EXACTLY a translation (what translate_top_left_mat is, reference src/stitch.cpp:70-74: the inverse of [1 0 -mx;
+// 0 1 -my; 0 0 1] in double is [1 0 mx; 0 1 my; 0 0 1] bit for bit), its rows are 16-byte aligned, and both boxes of a strip fit the
+// LDS slice of a wave.  Everything else takes the direct form (stitch_compose_kernel).
+static bool stitch_strip_plan(const StitchArgs& a, StitchLeft& sl, int& lds)
+{
+#ifdef DR3_STITCH_NO_STRIPS
+    return false;
+#endif
+    const WarpJobDev& jl = a.job[0];
+    const WarpJobDev& jr = a.job[1];
+    if (jr.tile != 2 || jr.tile_lds <= 0) return false;
+    const double* M = jl.M;
+    if (!(M[0] == 1.0 && M[1] == 0.0 && M[3] == 0.0 && M[4] == 1.0 && M[6] == 0.0 && M[7] == 0.0 && M[8] == 1.0)) return false;
+    if (!(std::fabs(M[2]) < 30000.0 && std::fabs(M[5]) < 30000.0) || a.dw > 30000 || a.dh > 30000) return false;      // taps stay inside saturate_cast<short>
+    if ((((uintptr_t)jl.src | (uintptr_t)jl.sstride) & 15) || jl.sstride >= (1 << 24) || jl.sh >= (1 << 24) || (long long)jl.sstride * jl.sh >= (1LL << 31)) return false;
+    // OpenCV: X = saturate_cast<int>((X0 + M0 * x1) * (32 / W)) = rint(32 x + 32 tx): 32 x is an even integer, the f64 operations are
+    // exact, so every pixel rounds like x = 0 does (round half to even): X = 32 x + K
+    const long long Kx = (long long)std::nearbyint(32.0 * M[2]), Ky = (long long)std::nearbyint(32.0 * M[5]);
+    sl.src = jl.src; sl.sw = jl.sw; sl.sh = jl.sh; sl.sstride = jl.sstride;
+    sl.ix = (int)(Kx >> 5); sl.iy = (int)(Ky >> 5);
+    const uint32_t fx = (uint32_t)(Kx & 31), fy = (uint32_t)(Ky & 31);          // blend8_weights on the host
+    sl.wlo = (32u - fx) | (fx << 8); sl.whi = sl.wlo << 16; sl.wy0 = (32u - fy) << 6; sl.wy1 = fy << 6; sl.fx = (int)fx; sl.fy = (int)fy;
+    sl.alpha = a.alpha; sl.beta = a.beta; sl.gamma = a.gamma;
+    sl.avg = (a.alpha == 0.5f && a.beta == 0.5f && a.gamma == 0.0f) ? 1 : 0;
+    lds = (std::max(jr.tile_lds, 1024) + 255) & ~255;
+    return lds <= kWarpTileLdsBytes;
+}
+
+bool stitch_takes_strips(const StitchArgs& a) { StitchLeft sl; int lds = 0; return stitch_strip_plan(a, sl, lds); }
+
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s)
 {
     if (a.dw <= 0 || a.dh <= 0) return hipSuccess;
     dim3 block(64, 4);
+    StitchDev sd;
+    int lds = 0;
+    if (stitch_strip_plan(a, sd.sl, lds)) {
+        sd.a = a;
+        const int tiles_x = (a.dw + kTileW - 1) / kTileW;
+        const long long n_tiles = (long long)tiles_x * ((a.dh + kTileH - 1) / kTileH);
+        if (n_tiles < (1LL << 30)) {
+            const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
+            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp), 1, 1);
+            hipLaunchKernelGGL(stitch_strip_kernel, tgrid, block, 4 * (lds + 256), s, sd, tiles_x, (int)n_tiles, lds, run);
+            return hipGetLastError();
+        }
+    }
     const int tw = WaveTile<4>::LX * 4, th = 4 * WaveTile<4>::LY;
     dim3 grid((a.dw + tw - 1) / tw, (a.dh + th - 1) / th, 1);
     if (a.job[0].bw0_shift < 0 || a.job[1].bw0_shift < 0) hipLaunchKernelGGL(stitch_compose_kernel<true>,  grid, block, 0, s, a);

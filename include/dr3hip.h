@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DR3HIP_VERSION 101
+#define DR3HIP_VERSION 102
 #define DR3HIP_BATCH_MAX_W 4000000   /* widest frame of a dr3hip_batch: the tracker addresses rows of 4 (w + 2 pad) + 16 bytes with 24-bit pitches */
 
 /* error codes */
@@ -357,6 +357,11 @@ int dr3hip_stitch_compose(dr3hip_ctx* ctx, const uint8_t* left, int lw, int lh, 
                           const uint8_t* right, int rw, int rh, int rstride,
                           const float T[9], const float M_right[9], int new_w, int new_h,
                           float alpha, float beta, float gamma, uint8_t* out, int ostride);
+/* Which form dr3hip_stitch_compose_dev runs, without running it: *kernel = 2 the strip form (the right image through the LDS-staged
+ * strip machinery of DESIGN.md 4.3.1, the left image as the exact translation it is, src/stitch.cpp:74), 0 the direct form (any
+ * matrices, any alignment).  Pointers and strides as they would be passed (only their alignment matters).  Host only. */
+int dr3hip_stitch_plan(const uint8_t* d_left, int lw, int lh, int lstride, const uint8_t* d_right, int rw, int rh, int rstride,
+                       const float T[9], const float M_right[9], int new_w, int new_h, float alpha, float beta, float gamma, int* kernel);
 /* the same with device pointers (no copies; enqueued on the ctx stream) */
 int dr3hip_stitch_compose_dev(dr3hip_ctx* ctx, const uint8_t* d_left, int lw, int lh, int lstride,
                               const uint8_t* d_right, int rw, int rh, int rstride,

@@ -29,4 +29,12 @@ for it, eps in ((30, 0.01), (0, 0.0), (30, 0.01)):
         batch.track(B, 0, d_prev, d_next, N, d_st, d_err, p)
     ms, n = ctx.profile_read(dr3.PROF_LK)
     out.append("iters %2d: %.3f ms" % (it, ms / n))
+for deriv in (True, False):          # the pyramid pass with and without the derivative planes (HIP events around the launches of one pass)
+    for rep in range(4):
+        batch.build(1, B, deriv)
+    ctx.sync(); ctx.profile_reset()
+    for rep in range(10):
+        batch.build(1, B, deriv)
+    ms, n = ctx.profile_read(dr3.PROF_PYR)
+    out.append("pyramid pass %s: %.3f ms" % ("+ Scharr" if deriv else "only", ms / max(n, 1)))
 print("%-28s win %d levels %d  %s" % (os.path.basename(os.environ.get("DR3HIP_LIB", "libdr3hip.so")), WIN, ML + 1, "   ".join(out)), flush=True)
