@@ -694,12 +694,13 @@ __device__ __forceinline__ void stitch_fallback_8uc3(const WarpJobDev& jr, const
 // Every job: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
 // (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
 template <bool STITCH>
-__device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const WarpJobDev* jl, const StitchLeft* slp, int t, int tiles_x, int lds_bytes, uint8_t* s_dyn)
+__device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const WarpJobDev* jl, const StitchLeft* slp, int t, int tiles_x, int lds_bytes, uint8_t* s_dyn,
+                                                int wv, int lds_slot)     // wv: the wave's strip of the tile; lds_slot: its slice of the block's LDS
 {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int tx0 = tx * kTileW, ty0 = ty * kTileH;
     const int dw = jb.dw, dh = jb.dh;
-    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int lane = threadIdx.x;
     const int x = tx0 + lane, y0 = ty0 + kWaveRows * wv;
     const int n_rows = min(kWaveRows, dh - y0);                             // wave-uniform
     if (tx0 >= dw || n_rows <= 0) return;
@@ -713,7 +714,7 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
     const bool src16 = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)sstride) & 15) == 0 &&
                        sstride < (1 << 24) && sh < (1 << 24) && (long long)sstride * sh < (1LL << 31);
     if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else tile_fallback_8uc3(jb, x, y0); return; }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)s_dyn + (uint32_t)wv * (uint32_t)(lds_bytes + 256);    // this wave's slice (LDS byte address)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)s_dyn + (uint32_t)lds_slot * (uint32_t)(lds_bytes + 256);    // this wave's slice (LDS byte address)
     const uint32_t list0 = lds0 + (uint32_t)lds_bytes;
 
     // anchor: (x, y0 + 7.5), f64; units: 2^-13 of 1/32 px
@@ -947,20 +948,24 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
     }
     const WarpJobDev& jb = jobs[job];
     if (t >= n_tiles) return;
-    strip_tile_body<false>(jb, nullptr, nullptr, t, tiles_x, lds_bytes, s_dyn);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    strip_tile_body<false>(jb, nullptr, nullptr, t, tiles_x, lds_bytes, s_dyn, wv, wv);
 }
 
 // the fused stitch on strips: a.job[1] (right image) through the strip machinery, a.job[0] (left image) in its translation form sl
 // (the records are kernel arguments: everything that takes them is inlined, so they stay in the kernarg segment and are read with scalar
 // loads -- a noinline callee would make every wave copy them to scratch, and a copy to device memory per call costs more than the kernel)
 struct StitchDev { StitchArgs a; StitchLeft sl; };
-__global__ __launch_bounds__(256) void stitch_strip_kernel(const StitchDev sd, int tiles_x, int n_tiles, int lds_bytes, int run)
+__global__ __launch_bounds__(64) void stitch_strip_kernel(const StitchDev sd, int tiles_x, int n_tiles, int lds_bytes, int run)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const int b = blockIdx.x, r = b & (8 * run - 1);
+    // ONE wave per workgroup: a stitch is a single short launch (a 6000 x 3200 canvas is 19 000 strips, under four rounds of the chip's
+    // wave slots), and a four-wave workgroup only retires when its slowest strip does -- the strips of a tile differ by up to 10x (both
+    // images, one, none).  Blocks bq, bq + 8 share an XCD; the four strips of a tile are the blocks 8 i + x, i = 4 k .. 4 k + 3, of XCD x
+    const int bq = blockIdx.x, wv = (bq >> 3) & 3, b = (bq & 7) + 8 * (bq >> 5), r = b & (8 * run - 1);
     const int t = (b - r) + (r & 7) * run + (r / 8);
     if (t >= n_tiles) return;
-    strip_tile_body<true>(sd.a.job[1], &sd.a.job[0], &sd.sl, t, tiles_x, lds_bytes, s_dyn);
+    strip_tile_body<true>(sd.a.job[1], &sd.a.job[0], &sd.sl, t, tiles_x, lds_bytes, s_dyn, wv, 0);
 }
 
 // MAPS = 0: (u, v) read from two f32 planes (cv::remap, reference src/utils.cpp:191).
@@ -1391,8 +1396,8 @@ hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s)
         const long long n_tiles = (long long)tiles_x * ((a.dh + kTileH - 1) / kTileH);
         if (n_tiles < (1LL << 30)) {
             const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
-            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp), 1, 1);
-            hipLaunchKernelGGL(stitch_strip_kernel, tgrid, block, 4 * (lds + 256), s, sd, tiles_x, (int)n_tiles, lds, run);
+            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp * 4), 1, 1);
+            hipLaunchKernelGGL(stitch_strip_kernel, tgrid, dim3(64, 1), lds + 256, s, sd, tiles_x, (int)n_tiles, lds, run);
             return hipGetLastError();
         }
     }

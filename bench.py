@@ -989,10 +989,12 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
         if have_gpu:                                       # iteration-levels per point and per lock-step group (what tools/lk_valu_mix.py weights by)
             d_it = ctx.alloc(NP * n * b.levels * 4)
             d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params, d_iters=d_it); sync()
-            it = d_it.download((NP, n, b.levels), np.int32).sum(2)
+            itl = d_it.download((NP, n, b.levels), np.int32)
+            it = itl.sum(2)
             ppw = int(kernel.split(",")[1])
             out[name]["mean_iteration_levels_per_point"] = float(it.mean())
             out[name]["mean_iteration_levels_of_slowest_in_group"] = float(it[:, :n // ppw * ppw].reshape(NP, -1, ppw).max(2).mean())
+            out[name]["executed_iteration_levels_per_wave"] = float(itl[:, :n // ppw * ppw].reshape(NP, -1, ppw, b.levels).max(2).sum(2).mean())
             d_it.free()
         for d in (d_prev, d_next, d_st, d_err):
             d.free()
@@ -1433,8 +1435,10 @@ def stitch_leg(dist, ctx, dr3, synth, sync, tile, steps):
             d.free()
     k_ms = ms / max(n, 1)
     alg = 2 * TW_ * TH_ * 3 + nw * nh * 3                 # both sources read once + the canvas written once
+    plan = dr3.stitch_plan(TW_, TH_, TW_, TH_, T, M, (nw, nh), lstride=3 * TW_, rstride=3 * TW_)
     return {"canvas": [nw, nh], "kernel_ms": k_ms, "verified_vs_oracle": ok, "buffer_sets_rotated": n_sets, "canvas_mpix_per_s": aggregate_rate(dist, nw * nh * steps / 1e6, el),
-            "roofline": {"kernel": "stitch_compose_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+            "kernel_plan": plan,
+            "roofline": {"kernel": "stitch_strip_kernel (right image on LDS-staged strips, left image as its translation)" if plan == 2 else "stitch_compose_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
             "replaces": "reference passes: warp right (3 r + 3 w per canvas px), warp left (3 r + 3 w), addWeighted (6 r + 3 w)"}
 
