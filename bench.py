@@ -358,6 +358,8 @@ def main(argv=None):
     ap.add_argument("--sharded-paste", default=None, metavar="WxH", help="N > 1: run the canvas-sharded paste leg (one panorama per step across "
                     "the job) on tiles of this size even with --no-warp (default with the warp leg: 4000x3000)")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detect -> track front-end leg")
+    ap.add_argument("--no-hd-share", action="store_true", help="skip the bounded configs[4] leg (it launches the 21x21 tracker at a second shape, which a "
+                    "profiler pass that attributes counters per kernel symbol must not mix with the configs[0] leg's)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-buffer leg (its single-pair launches "
                     "share kernel symbols with the timed region and would skew a profiler's per-kernel averages)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -579,7 +581,7 @@ def main(argv=None):
 
     # ---- configs[4], one GPU's share, bounded (64 pairs, 5 timed steps): the driver's default line carries it ---------------------
     hd_share = None
-    if args.workload == "kitti" and not args.no_frontend and have_gpu:
+    if args.workload == "kitti" and not args.no_frontend and not args.no_hd_share and have_gpu:
         hd_share = hd_share_leg(dist, ctx, dr3, synth, sync)
 
     # ---- configs[2]: panorama backward warp, 8 tiles 4000x3000 -----------------------------------------

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 # libraries (product and oracle) are built before the first profiler line: build tools must not start under the profiler
 ( cd $R && python3 -c "import __graft_entry__ as g; g.build()" > /dev/null )
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-host-api $@"
+ARGS="--steps 2 --warmup 1 --no-cpu --no-warp --no-host-api --no-hd-share $@"
 run() { n=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_lk_$n -o p -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_lk_$n.log 2>&1 || echo "pmc $n failed"
 }

@@ -14,5 +14,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_hd_write -o write -- python3 $R/bench.py --workload hd --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/pmc_hd_write.log 2>&1
 # every leg of the default line but the warp leg (tools/profile_warp.sh has those) and the CPU baseline: detector, post-LK geometry,
 # sparse alignment, the other tracker windows, the real-frame leg -- so that every kernel of the product has a duration row
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_all -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-host-api --no-warp > $R/gpurun_out/prof_all.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_all -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-host-api --no-warp --no-hd-share > $R/gpurun_out/prof_all.log 2>&1
 ls -R $R/gpurun_out | head -50
