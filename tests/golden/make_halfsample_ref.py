@@ -1,4 +1,4 @@
-"""Makes tests/golden/halfsample_sse2_ref.npz: outputs of the REFERENCE'S OWN halfSampleSSE2 (reference src/utils.cpp:324-349), executed
+"""Makes tests/golden/halfsample_sse2_ref.npz and tests/golden/linspace_ref.npz: outputs of the REFERENCE'S OWN halfSampleSSE2 (reference src/utils.cpp:324-349), executed
 in the build container through oracle/_ref/libdr3ref_halfsample.so (`make -C oracle ref` compiles the function from where it lies under
 /root/reference; nothing of its source is stored here).  The fixture is data: input planes (seeded random + every rounding case of the
 two averaging stages) and the bytes the reference produced.  It pins row a4's SSE2 arithmetic -- the path utils::reduce_to_half takes
@@ -52,6 +52,19 @@ def main():
         out["ref_" + name] = dst.copy()
     np.savez_compressed(os.path.join(HERE, "halfsample_sse2_ref.npz"), **out)
     print("wrote halfsample_sse2_ref.npz:", {k: v.shape for k, v in out.items() if k.startswith("ref_")})
+    # utils::linspace<float> (reference include/utils.hpp:36-46): the feather ramps of Panorama::add_img_to_canvas are
+    # linspace(0, 1, w) and linspace(1, 0, w) (src/panorama.cpp:171-172); the accumulating `val += h` is what makes them differ from
+    # a closed form in the last bits.  Widths: the reference's feathering widths and the degenerate ones (N = 1 divides by zero: inf / nan)
+    L.dr3ref_linspace_f32.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p]
+    L.dr3ref_linspace_f32.restype = None
+    lin = {}
+    for n in (1, 2, 3, 7, 50, 51, 100, 299, 300, 301, 640, 1000, 4000):
+        for name, (a, b) in (("up", (0.0, 1.0)), ("down", (1.0, 0.0))):
+            o = np.zeros(n, np.float32)
+            L.dr3ref_linspace_f32(a, b, n, o.ctypes.data)
+            lin["%s_%d" % (name, n)] = o
+    np.savez_compressed(os.path.join(HERE, "linspace_ref.npz"), **lin)
+    print("wrote linspace_ref.npz:", len(lin), "vectors")
 
 
 if __name__ == "__main__":

@@ -68,3 +68,43 @@ def test_hip_pyramid_of_1920_wide_levels_follows_the_reference_chain(dr3, ctx):
     assert np.array_equal(got[1], ref[:16])
     for l in range(1, 4):
         assert np.array_equal(got[l], want[l]), l
+
+
+# ---- utils::linspace<float>, the feather ramps' building block (row f1), pinned the same way -----------------------------------------
+LIN = os.path.join(ROOT, "tests", "golden", "linspace_ref.npz")
+
+
+def test_oracle_linspace_equals_the_reference_outputs(O):
+    z = np.load(LIN)
+    assert len(z.files) == 26
+    for k in z.files:
+        kind, n = k.split("_"); n = int(n)
+        a, b = (0.0, 1.0) if kind == "up" else (1.0, 0.0)
+        got = O.linspace_f32(a, b, n)
+        assert np.array_equal(got.view(np.uint32), z[k].view(np.uint32)), k          # bit for bit, the inf / nan of N = 1 included
+
+
+def test_feather_ramp_is_built_from_those_vectors(O):
+    """Panorama::add_img_to_canvas (src/panorama.cpp:163-177): left ramp | ones | right ramp; the oracle's and the product's host
+    function (dr3hip_panorama_ramp) must hold the reference-produced linspace values at both ends"""
+    import importlib
+    dr3 = importlib.import_module("3dr_amd")
+    z = np.load(LIN)
+    for width, fw in ((1000, 300), (700, 50), (640, 100)):
+        ramp = O.feather_ramp(0, width, fw)
+        assert np.array_equal(ramp[:fw].view(np.uint32), z["up_%d" % fw].view(np.uint32))
+        assert np.array_equal(ramp[-fw:].view(np.uint32), z["down_%d" % fw].view(np.uint32))
+        assert np.all(ramp[fw:-fw] == 1.0)
+        assert np.array_equal(dr3.panorama_ramp(0, width, fw).view(np.uint32), ramp.view(np.uint32))
+
+
+def test_linspace_live_against_the_reference_function(O):
+    lib = os.path.join(ROOT, "oracle", "_ref", "libdr3ref_halfsample.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref is built in the build container only (make -C oracle ref)")
+    L = C.CDLL(lib)
+    L.dr3ref_linspace_f32.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p]
+    for a, b, n in ((0.0, 1.0, 77), (1.0, 0.0, 123), (-3.5, 9.25, 1024), (0.1, 0.7, 5)):
+        o = np.zeros(n, np.float32)
+        L.dr3ref_linspace_f32(a, b, n, o.ctypes.data)
+        assert np.array_equal(O.linspace_f32(a, b, n).view(np.uint32), o.view(np.uint32)), (a, b, n)
