@@ -33,7 +33,7 @@ LK_LOST_START_OUTSIDE, LK_LOST_MIN_EIG, LK_LOST_ITERATE_OUTSIDE, LK_LOST_RESULT_
 WARP_INVERSE_MAP = 16
 CRIT_COUNT, CRIT_EPS = 1, 2
 HALF_TRUNC, HALF_SSE2, HALF_REF_SCALAR, HALF_REF_X86 = 0, 1, 2, 3
-MAX_LEVELS, MAX_WIN = 8, 32
+MAX_LEVELS, MAX_WIN = 8, 64
 PROF_PYR, PROF_LK, PROF_WARP, PROF_REMAP, PROF_HALF, PROF_PYR_L0, PROF_PANO_ADD, PROF_PANO_NORM, PROF_FAST, PROF_STITCH, PROF_ALIGN = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 COMM_ID_BYTES = 128
 WARP_SPHERICAL, WARP_CYLINDRICAL = 1, 2

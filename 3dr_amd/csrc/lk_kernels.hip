@@ -2,7 +2,7 @@
 // cv::calcOpticalFlowPyrLK as called at reference src/initialization.cpp:608-613
 // (LKTrackerInvoker).
 //
-// One kernel shape for every window up to 32 x 32.  A lane owns taps of ONE window column: the window is cut into lane-items of
+// One kernel shape for every window up to 32 x 32 (sides 33 .. 64: lk_track_big_kernel at the end of this file).  A lane owns taps of ONE window column: the window is cut into lane-items of
 // consecutive rows of a column -- windows up to 16 x 16: the whole column (up to 16 taps); other windows: 8 rows, item
 // q = (ty / 8) * win_w + tx.  A point is tracked by a GROUP of 64 / PPW lanes, a lane owns the items hl, hl + LANES, ... (NI of
 // them), and a wave tracks PPW points in lock step:
@@ -639,6 +639,156 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     }
 }
 
+
+// ---- windows beyond 32 x 32 (up to DR3HIP_MAX_WIN = 64): the plain form ----------------------------------------------------------------
+// cv::calcOpticalFlowPyrLK has no window limit; the reference's own 30 x 30 and every BASELINE configuration run on the kernel above,
+// and this one only removes the limit: ONE wave per point, the same cut of the window into lane-items of 8 rows of a column
+// (item q = (ty / 8) * win_w + tx on lane q % 64 -- the summation order the CPU checker's kernel order states for any window), the
+// interpolated template (I, Ix, Iy as int16) in LDS, the search image read from the padded planes tap by tap.  Lane sums in int64
+// (a lane may hold 64 taps of 2^25), converted to f32 once, then the wave tree.  Not tuned.
+__global__ __launch_bounds__(64) void lk_track_big_kernel(const LKArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    int16_t* __restrict__ tI = reinterpret_cast<int16_t*>(lds_all);                  // [win_h * win_w]
+    const int win_w = a.win_w, win_h = a.win_h, n_taps = win_w * win_h;
+    int16_t* __restrict__ tX = tI + ((n_taps + 7) & ~7);
+    int16_t* __restrict__ tY = tX + ((n_taps + 7) & ~7);
+    const int lane = threadIdx.x, pair = blockIdx.y, pt = blockIdx.x;
+    const long long pidx = (long long)pair * a.n_pts + pt;
+    const int ps = a.prev_slot ? a.prev_slot[pair] : a.first_slot + pair;
+    const int ns = a.next_slot ? a.next_slot[pair] : a.first_slot + pair + 1;
+    const float ppx = a.prev_xy[2 * pidx], ppy = a.prev_xy[2 * pidx + 1];
+    float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
+    const int nblk = (win_h + 7) >> 3, n_items = win_w * nblk;
+    const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    int lost = 0;
+    float err = 0.f;
+
+    for (int level = a.max_level; level >= 0; --level) {
+        const LevelDev& L = a.lv[level];
+        const int Lw = L.w, Lh = L.h, pitch = L.pitch, dpitch = L.dpitch;
+        const uint8_t* __restrict__ Ip = L.img + (long long)ps * L.step;               // interior origins: negative offsets reach the border
+        const uint8_t* __restrict__ Jp = L.img + (long long)ns * L.step;
+        const int16_t* __restrict__ Dp = reinterpret_cast<const int16_t*>(reinterpret_cast<const uint8_t*>(L.der) + (long long)ps * L.dstep);
+        const float scale = __int_as_float((127 - level) << 23);
+        float px = ppx * scale, py = ppy * scale, cx, cy;
+        if (level == a.max_level) {
+            if (a.flags & DR3HIP_LK_USE_INITIAL_FLOW) { cx = nx * scale; cy = ny * scale; } else { cx = px; cy = py; }
+        } else { cx = nx * 2.f; cy = ny * 2.f; }
+        nx = cx; ny = cy;
+        int it_count = 0;
+        px -= half_x; py -= half_y;
+        const float fpx = floorf(px), fpy = floorf(py);
+        const int ipx = floor_to_int(fpx), ipy = floor_to_int(fpy);
+        const bool inside = (unsigned)(ipx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(ipy + win_h) < (unsigned)(Lh + win_h);
+        if (!inside) {                                                                  // wave-uniform
+            if (level == 0) { lost = DR3HIP_LK_LOST_START_OUTSIDE; err = 0.f; }
+            if (a.iters && lane == 0) a.iters[pidx * (a.max_level + 1) + level] = 0;
+            continue;
+        }
+        // ---- template + structure tensor
+        long long s11 = 0, s12 = 0, s22 = 0;
+        {
+            const Weights W = make_weights(px - fpx, py - fpy);
+            const int w00 = (int16_t)(W.w01 & 0xffffu), w01 = (int16_t)(W.w01 >> 16), w10 = (int16_t)(W.w23 & 0xffffu), w11 = (int16_t)(W.w23 >> 16);
+            for (int q = lane; q < n_items; q += 64) {
+                const int blk = q / win_w, tx = q - blk * win_w;
+                const int y1 = min(8 * blk + 8, win_h);
+                for (int ty = 8 * blk; ty < y1; ++ty) {
+                    const uint8_t* r0 = Ip + (long long)(ipy + ty) * pitch + (ipx + tx);
+                    const uint8_t* r1 = r0 + pitch;
+                    const int16_t* d0 = reinterpret_cast<const int16_t*>(reinterpret_cast<const uint8_t*>(Dp) + (long long)(ipy + ty) * dpitch) + 2 * (ipx + tx);
+                    const int16_t* d1 = reinterpret_cast<const int16_t*>(reinterpret_cast<const uint8_t*>(d0) + dpitch);
+                    const int iv = (r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                    const int gx = (d0[0] * w00 + d0[2] * w01 + d1[0] * w10 + d1[2] * w11 + (1 << (W_BITS - 1))) >> W_BITS;
+                    const int gy = (d0[1] * w00 + d0[3] * w01 + d1[1] * w10 + d1[3] * w11 + (1 << (W_BITS - 1))) >> W_BITS;
+                    const int k = ty * win_w + tx;
+                    tI[k] = (int16_t)iv; tX[k] = (int16_t)gx; tY[k] = (int16_t)gy;
+                    s11 += gx * gx; s12 += gx * gy; s22 += gy * gy;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float A11, A12, A22;
+        wave_sum3((float)s11, (float)s12, (float)s22, A11, A12, A22);
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win_w * win_h);
+        if (a.flags & DR3HIP_LK_GET_MIN_EIGENVALS) err = minEig;
+        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-7f) {
+            if (level == 0) lost = DR3HIP_LK_LOST_MIN_EIG;
+            if (a.iters && lane == 0) a.iters[pidx * (a.max_level + 1) + level] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        cx -= half_x; cy -= half_y;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_count; ++j) {
+            const float fcx = floorf(cx), fcy = floorf(cy);
+            const int inx = floor_to_int(fcx), iny = floor_to_int(fcy);
+            if (!((unsigned)(inx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(iny + win_h) < (unsigned)(Lh + win_h))) {
+                if (level == 0) lost = DR3HIP_LK_LOST_ITERATE_OUTSIDE;
+                break;
+            }
+            it_count = j + 1;
+            const Weights W = make_weights(cx - fcx, cy - fcy);
+            const int w00 = (int16_t)(W.w01 & 0xffffu), w01 = (int16_t)(W.w01 >> 16), w10 = (int16_t)(W.w23 & 0xffffu), w11 = (int16_t)(W.w23 >> 16);
+            long long s1 = 0, s2 = 0;
+            for (int q = lane; q < n_items; q += 64) {
+                const int blk = q / win_w, tx = q - blk * win_w;
+                const int y1 = min(8 * blk + 8, win_h);
+                for (int ty = 8 * blk; ty < y1; ++ty) {
+                    const uint8_t* r0 = Jp + (long long)(iny + ty) * pitch + (inx + tx);
+                    const uint8_t* r1 = r0 + pitch;
+                    const int k = ty * win_w + tx;
+                    const int diff = ((r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - tI[k];
+                    s1 += diff * tX[k]; s2 += diff * tY[k];
+                }
+            }
+            float b1, b2;
+            wave_sum2((float)s1, (float)s2, b1, b2);
+            b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            cx += dx; cy += dy;
+            nx = cx + half_x; ny = cy + half_y;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) { nx -= dx * 0.5f; ny -= dy * 0.5f; break; }
+            pdx = dx; pdy = dy;
+        }
+        if (a.iters && lane == 0) a.iters[pidx * (a.max_level + 1) + level] = it_count;
+
+        if (level == 0 && !(a.flags & DR3HIP_LK_GET_MIN_EIGENVALS) && lost == 0) {
+            const float fx = nx - half_x, fy = ny - half_y;
+            const float ffx = floorf(fx), ffy = floorf(fy);
+            const int inx = floor_to_int(ffx), iny = floor_to_int(ffy);
+            if (!((unsigned)(inx + win_w) < (unsigned)(Lw + win_w) && (unsigned)(iny + win_h) < (unsigned)(Lh + win_h))) { lost = DR3HIP_LK_LOST_RESULT_OUTSIDE; continue; }
+            const Weights W = make_weights(fx - ffx, fy - ffy);
+            const int w00 = (int16_t)(W.w01 & 0xffffu), w01 = (int16_t)(W.w01 >> 16), w10 = (int16_t)(W.w23 & 0xffffu), w11 = (int16_t)(W.w23 >> 16);
+            long long se = 0;
+            for (int q = lane; q < n_items; q += 64) {
+                const int blk = q / win_w, tx = q - blk * win_w;
+                const int y1 = min(8 * blk + 8, win_h);
+                for (int ty = 8 * blk; ty < y1; ++ty) {
+                    const uint8_t* r0 = Jp + (long long)(iny + ty) * pitch + (inx + tx);
+                    const uint8_t* r1 = r0 + pitch;
+                    const int diff = ((r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - tI[ty * win_w + tx];
+                    se += diff < 0 ? -diff : diff;
+                }
+            }
+            err = wave_sum1((float)se) * 1.f / (float)(32 * win_w * win_h);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        a.next_xy[2 * pidx] = nx;
+        a.next_xy[2 * pidx + 1] = ny;
+        a.status[pidx] = (uint8_t)(lost == 0);
+        if (a.reason) a.reason[pidx] = (uint8_t)lost;
+        a.err[pidx] = err;
+    }
+}
+
 }  // namespace
 
 // ---- counters over the tracker's outputs (dr3hip_lk_stats): per-wave ballots / LDS histogram, one atomic per counter and block -----
@@ -690,7 +840,12 @@ static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
 hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const LaunchEv* ev)
 {
     if (n_pairs <= 0 || a.n_pts <= 0) return hipSuccess;
-    if (a.win_w < 3 || a.win_h < 3 || a.win_w > 32 || a.win_h > 32) return hipErrorInvalidValue;
+    if (a.win_w < 3 || a.win_h < 3 || a.win_w > DR3HIP_MAX_WIN || a.win_h > DR3HIP_MAX_WIN) return hipErrorInvalidValue;
+    if (a.win_w > 32 || a.win_h > 32) {                 // the plain form: one wave per point, template in LDS
+        const size_t taps = ((size_t)a.win_w * a.win_h + 7) & ~(size_t)7;
+        DR3_LAUNCH(ev, lk_track_big_kernel, dim3(a.n_pts, n_pairs), dim3(64), 3 * taps * sizeof(int16_t), s, a);
+        return hipGetLastError();
+    }
     int ppw, ni;
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
     const bool wide = LKG_WIDE != 0;

@@ -32,7 +32,7 @@ extern "C" {
 #define DR3HIP_ENODEV   -2   /* no usable HIP device              */
 #define DR3HIP_ENOMEM   -3   /* device or host allocation failed  */
 #define DR3HIP_EHIP     -4   /* HIP runtime error (see last_error) */
-#define DR3HIP_ERANGE   -5   /* parameter outside the supported range (e.g. window > 32) */
+#define DR3HIP_ERANGE   -5   /* parameter outside the supported range (e.g. window > 64) */
 
 /* pixel types (the three the reference passes to the warp calls, plus two for generality) */
 #define DR3HIP_8UC1   0      /* gray,  cv CV_8UC1                                  */
@@ -57,7 +57,7 @@ extern "C" {
 #define DR3HIP_HALF_REF_X86     3   /* what the reference executes on x86-64: SSE2 if cols%16==0 else REF_SCALAR */
 
 #define DR3HIP_MAX_LEVELS       8   /* pyramid levels 0..7 */
-#define DR3HIP_MAX_WIN         32   /* LK window side limit of this build */
+#define DR3HIP_MAX_WIN         64   /* LK window side limit of this build (sides up to 32: the tuned kernels; 33 .. 64: a plain form) */
 
 typedef struct dr3hip_ctx   dr3hip_ctx;
 typedef struct dr3hip_batch dr3hip_batch;

@@ -179,6 +179,7 @@ enum { WSUM_A = 0, WSUM_B = 1, WSUM_E = 2 };
  * DR3O_ORDER_WAVE64 follows whichever applies. */
 static int kernel_points_per_wave(int win_w, int win_h)
 {
+    if (win_w > 32 || win_h > 32) return 1;             /* the plain form for windows beyond 32 x 32 (lk_track_big_kernel): always a whole wave */
     if (win_w <= 16 && win_h <= 16) return 8;           /* an EIGHTH of a wave: 8 lanes, lane = columns c and c + 8 */
     if (win_w * ((win_h + 7) / 8) <= 64) return 2;
     return 1;

@@ -303,10 +303,10 @@ def test_empty_point_set(dr3, ctx, synth):
 
 
 def test_bad_arguments_return_errors(dr3, ctx):
-    A = np.zeros((64, 64), np.uint8)
+    A = np.zeros((96, 96), np.uint8)
     pts = np.array([[10, 10]], np.float32)
     with pytest.raises(dr3.Dr3HipError):
-        ctx.calcOpticalFlowPyrLK(A, A, pts, None, dr3.lk_params(win=(40, 40), max_level=1))   # window too large
+        ctx.calcOpticalFlowPyrLK(A, A, pts, None, dr3.lk_params(win=(65, 65), max_level=1))   # window beyond DR3HIP_MAX_WIN
     with pytest.raises(dr3.Dr3HipError):
         ctx.calcOpticalFlowPyrLK(A, A, pts, None, dr3.lk_params(win=(2, 2), max_level=1))
 
@@ -377,3 +377,26 @@ def test_batch_track_with_slot_indirection(dr3, O, synth, ctx):
         for d in bufs:
             d.free()
         b.close()
+
+
+@pytest.mark.parametrize("win", [(33, 33), (41, 37), (64, 64), (48, 20), (20, 50), (10, 40), (40, 8), (64, 3)])
+def test_windows_beyond_32_run_on_the_plain_kernel(dr3, O, synth, ctx, win):
+    """cv::calcOpticalFlowPyrLK has no window limit; sides 33 .. 64 run on lk_track_big_kernel (one wave per point, the same lane-item
+    cut of the window, int64 lane sums): bit-exact against the oracle's kernel order, both flags, points on and beyond the borders"""
+    A, B, T = synth.frame_pair(400, 300)
+    rng = np.random.default_rng(win[0] * 100 + win[1])
+    pts = np.concatenate([synth.grid_points(400, 300, 45, border=4),
+                          np.stack([rng.uniform(-30, 430, 40), rng.uniform(-30, 330, 40)], 1).astype(np.float32),
+                          np.array([[np.nan, 10], [10, np.inf], [dr3.NO_POINT, dr3.NO_POINT]], np.float32)])
+    for flags in (0, dr3.LK_USE_INITIAL_FLOW, dr3.LK_GET_MIN_EIGENVALS):
+        kw = dict(win=win, max_level=3, max_iters=12, eps=0.02, flags=flags)
+        pg, po = _params(dr3, O, **kw)
+        guess = pts + rng.uniform(-1.0, 1.0, pts.shape).astype(np.float32) if flags & dr3.LK_USE_INITIAL_FLOW else None
+        g_xy, g_st, g_err, g_L = ctx.calcOpticalFlowPyrLK(A, B, pts, guess, pg)
+        w_xy, w_st, w_err, w_L = O.lk_track(A, B, pts, guess, po, order=O.ORDER_WAVE64)
+        assert g_L == w_L
+        assert np.array_equal(g_st, w_st), (win, flags)
+        assert np.array_equal(g_xy.view(np.uint32), w_xy.view(np.uint32)), (win, flags)
+        assert np.array_equal(g_err.view(np.uint32), w_err.view(np.uint32)), (win, flags)
+    ok = g_st == 1
+    assert ok.sum() > 20

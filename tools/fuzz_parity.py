@@ -33,6 +33,10 @@ for case in range(n_cases):
     win = (int(rng.integers(3, 33)), int(rng.integers(3, 33)))
     if rng.random() < 0.25:                        # the compile-time window instantiations
         win = [(15, 15), (21, 21), (30, 30)][int(rng.integers(0, 3))]
+    elif rng.random() < 0.08:                      # sides beyond 32: the plain kernel (lk_track_big_kernel)
+        win = (int(rng.integers(3, 65)), int(rng.integers(33, 65)))
+        if rng.random() < 0.5:
+            win = win[::-1]
     if w <= win[0] + 2 or h <= win[1] + 2:
         continue
     ml = int(rng.integers(0, 6)); flags = int(rng.choice([0, 4, 8, 12]))
