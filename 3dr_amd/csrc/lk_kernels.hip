@@ -167,6 +167,9 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef LKG_WAVES_NI2
 #define LKG_WAVES_NI2 4
 #endif
+#ifndef LKG_WAVES_NI4
+#define LKG_WAVES_NI4 3       // four points per wave, four 8-row items per lane (21 x 21)
+#endif
 #ifndef LKG_WAVES_P8
 #define LKG_WAVES_P8 3       // eight points per wave: two 16-tap columns per lane
 #endif
@@ -184,21 +187,30 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 // WIN > 0: square compile-time window; WIN = 0: run-time window of the group shape PPW x NI (lk_group_shape below)
 template <int WIN, int PPW, int NI>
 // (the run-time forms holding 16 taps per lane need more registers than four waves per SIMD leave them)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (WIN ? LKG_WAVES_P8 : 2) : (WIN == 0 && NI * (PPW == 4 ? 16 : 8) == 16) ? 3 : (NI == 2 ? LKG_WAVES_NI2 : LKG_WAVES)))) void lk_trackg_kernel(const LKArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (WIN ? LKG_WAVES_P8 : 2) : NI == 4 ? LKG_WAVES_NI4 : (WIN == 0 && NI * (PPW == 4 ? 16 : 8) == 16) ? 3 : (NI == 2 ? LKG_WAVES_NI2 : LKG_WAVES)))) void lk_trackg_kernel(const LKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     constexpr int LANES = 64 / PPW;               // lanes per point
     constexpr bool WIDE = LKG_WIDE != 0;
     constexpr bool PRE = WIDE && WIN != 0 && LKG_PRE;          // the template's derivative loads are issued with the staging loads
-    constexpr int NT = PPW >= 4 ? 16 : 8;         // taps (consecutive window rows of one column) per lane-item
-    constexpr int COLS = PPW >= 4 ? 8 : 16;       // dword columns of the staging grid (>= the region's width)
-    constexpr int SR = LANES / COLS;              // rows a group stages per round
+#ifndef LKG_PRE_ITEMS4
+#define LKG_PRE_ITEMS4 4
+#endif
+    constexpr int PRE_ITEMS = NI == 4 ? LKG_PRE_ITEMS4 : NI;  // ... those of the first PRE_ITEMS lane-items (four items of 9 rows are 72 registers)
+    // COLF: the column form -- a lane-item is a whole window column (<= 16 taps): an eighth of a wave with two columns per lane, or a
+    // quarter with one.  Otherwise items are 8 rows of a column; <21, 4, 4> is that form on a QUARTER wave, four items per lane
+    constexpr bool COLF = PPW == 8 || (PPW == 4 && NI == 1);
+    constexpr int NT = COLF ? 16 : 8;             // taps (consecutive window rows of one column) per lane-item
+    // dword columns of the staging grid (>= the region's width: window + 1 + 2 RM + 3 bytes of alignment); an even number (8-byte pieces)
+    constexpr int COLS = COLF ? 8 : (WIN && PPW == 4) ? (((WIN + 2 * RM + 4 + 3) / 4 + 1) & ~1) : 16;
+    constexpr int SR = LANES / COLS > 0 ? LANES / COLS : 1;      // rows a group stages per round (the narrow staging only)
     // WIDE staging: a row is fetched as PCS pieces of 8 bytes (4 COLS bytes: the J region's row and the template's image row both fit),
     // a round of the group's lanes covers RPR rows
     constexpr int PCS = COLS / 2, RPR = LANES / PCS, IPITCH = COLS + 1;
+    constexpr bool SPARE = RPR * PCS != LANES;    // lanes behind the last whole row of a round (16 lanes, 5 pieces): they load, but do not store
     // staged template image rows per point: the rows its lane-items read (a whole column + 1, or 8-row items up to 8 nblk + 1), in whole rounds
-    constexpr int IROWS = ((WIN ? (PPW >= 4 ? WIN + 1 : 8 * ((WIN + 7) / 8) + 1) : (PPW >= 4 ? 17 : 33)) + RPR - 1) / RPR * RPR;
-    static_assert((PPW != 4 || NI == 1) && (PPW != 8 || NI == 2), "a quarter wave holds one window column per lane, an eighth two");
+    constexpr int IROWS = ((WIN ? (COLF ? WIN + 1 : 8 * ((WIN + 7) / 8) + 1) : (COLF ? 17 : 33)) + RPR - 1) / RPR * RPR;
+    static_assert((PPW != 4 || NI == 1 || NI == 4) && (PPW != 8 || NI == 2), "a quarter wave holds one window column per lane (or four 8-row items), an eighth two columns");
 
     const int lane = threadIdx.x, hl = lane & (LANES - 1), grp = lane / LANES;
     const int pair = blockIdx.y;
@@ -213,14 +225,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     float nx = a.next_xy[2 * pidx], ny = a.next_xy[2 * pidx + 1];
 
     const int win_w = WIN ? WIN : a.win_w, win_h = WIN ? WIN : a.win_h;
-    const int nblk = PPW >= 4 ? 1 : (win_h + 7) >> 3;      // lane-items per window column
+    const int nblk = COLF ? 1 : (win_h + 7) >> 3;          // lane-items per window column
     const int rwd = (win_w + 15) >> 2, rh = win_h + 9, lpd = WIDE ? COLS + 1 : rwd | 1;    // staged J region: dwords per row, rows, LDS row pitch (odd; WIDE: PCS pieces of 2 dwords + 1)
     // LDS rows per group: staging runs in rounds of SR rows.  Every form but the compile-time column forms (WIN with PPW >= 4, whose
     // tap_live() stops at the window) also reads (and masks) the rows of the taps below the window: a lane-item of NT rows starting at
     // ity, up to 8 rows into the region, reaches row 8 + ity + NT <= win_h + 15 of the slice
     constexpr int SRW = WIDE ? RPR : SR;          // rows per staging round
-    const int rhs = (((WIN && PPW >= 4) ? rh : PPW >= 4 ? 25 : win_h + 16) + SRW - 1) / SRW * SRW;
-    static_assert(!(WIN && PPW < 4) || 8 + 8 * ((WIN + 7) / 8 - 1) + 8 <= WIN + 15, "the slice of a group holds every row its lane-items read");
+    const int rhs = (((WIN && COLF) ? rh : COLF ? 25 : win_h + 16) + SRW - 1) / SRW * SRW;
+    static_assert(!(WIN && !COLF) || 8 + 8 * ((WIN + 7) / 8 - 1) + 8 <= WIN + 15, "the slice of a group holds every row its lane-items read");
     const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps_lo = (float)(a.epsilon * (1.0 - 1e-6)), eps_hi = (float)(a.epsilon * (1.0 + 1e-6));
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     for (int i = 0; i < NI; ++i) {
         const int q = hl + i * LANES;
         const bool ivalid = q < win_w * nblk;
-        const int blk = (PPW >= 4 || !ivalid) ? 0 : (q >= win_w) + (q >= 2 * win_w) + (q >= 3 * win_w);
+        const int blk = (COLF || !ivalid) ? 0 : (q >= win_w) + (q >= 2 * win_w) + (q >= 3 * win_w);
         itx[i] = ivalid ? q - blk * win_w : 0;
         ity[i] = 8 * blk;
         loffB[i] = (uint32_t)(ity[i] * lpd) * 4u;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
     }
     // int16-pair mask of taps (2h, 2h+1) of item i: all ones, the low half only, or nothing.  With a compile-time window and one
     // item per column the pattern is a constant per h, and the idle lanes are removed from the lane sums instead (lane_mask)
-    constexpr bool LANE_MASKED = WIN && PPW == 4;
+    constexpr bool LANE_MASKED = WIN && PPW == 4 && NI == 1;
     const int lane_mask = ntap[0] ? -1 : 0;
     // an eighth of a wave with a compile-time window: the pattern is a constant per h as well, but the lane's second column may lie
     // beyond the window (column 15 of a 15-wide one): its gradients are zeroed through item_mask
@@ -257,14 +269,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
         return ntap[i] >= 2 * h + 2 ? 0xffffffffu : (ntap[i] == 2 * h + 1 ? 0x0000ffffu : 0u);
     };
     // a quarter wave with a compile-time window: the taps below the window are not computed at all
-    auto tap_live = [](int k) -> bool { return !(WIN && PPW >= 4) || k < WIN; };
+    auto tap_live = [](int k) -> bool { return !(WIN && COLF) || k < WIN; };
     // staging grid of the group: SR rows x COLS dword columns per round
     const int sc = hl & (COLS - 1), sr = hl / COLS;
     uint32_t* __restrict__ lds_st = lds + sr * lpd + sc;
     // WIDE: the J region rows [ry, ry + rh) x bytes [rx, rx + 32) of the current level into the group's slice: lane = (row of a pair, 8-byte piece)
     gbase_t Jb = nullptr; int Jpitch = 0, Jpad_x = 0, Jpad_y = 0;            // set per level
     auto stage_J_wide = [&](int rx, int ry) {
-        const int rr = hl / PCS, pc = hl & (PCS - 1);
+        const int rr = hl / PCS, pc = hl - rr * PCS;
+        const bool stg = !SPARE || rr < RPR;
         uint32_t off = __umul24((unsigned)(ry + Jpad_y + rr), (unsigned)Jpitch) + (unsigned)(rx + Jpad_x + 8 * pc);
         uint32_t* st = lds + rr * lpd + 2 * pc;
         if (WIN) {
@@ -272,10 +285,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
             u32x2 v[JR];
 #pragma unroll
             for (int k = 0; k < JR; ++k) { v[k] = ldg<u32x2>(Jb, off); off += (unsigned)RPR * (unsigned)Jpitch; }
+            if (stg) {
 #pragma unroll
-            for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = v[k].x; st[RPR * k * lpd + 1] = v[k].y; }
+                for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = v[k].x; st[RPR * k * lpd + 1] = v[k].y; }
+            }
         } else {
-            for (int r = rr; r < rh; r += RPR) { const u32x2 v = ldg<u32x2>(Jb, off); st[(r - rr) * lpd] = v.x; st[(r - rr) * lpd + 1] = v.y; off += (unsigned)RPR * (unsigned)Jpitch; }
+            for (int r = rr; r < rh && stg; r += RPR) { const u32x2 v = ldg<u32x2>(Jb, off); st[(r - rr) * lpd] = v.x; st[(r - rr) * lpd + 1] = v.y; off += (unsigned)RPR * (unsigned)Jpitch; }
         }
     };
 
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
         // [x0, x0 + 4*rwd).  A start outside the level is rejected by the first iteration's bounds test; the staging
         // centre is clamped so that the (unused) region stays inside the padded plane.
         int rx0, ry0;                      // interior coordinates of LDS (row 0, byte 0) of this group's region; rx0 is a multiple of 4
-        u32x2 ddv[PRE ? NI : 1][PRE ? NT + 1 : 1];       // PRE: the template's derivative rows, loaded ahead
+        u32x2 ddv[PRE ? PRE_ITEMS : 1][PRE ? NT + 1 : 1];       // PRE: the template's derivative rows, loaded ahead
         {
             const int sx = floor_to_int(floorf(cx)), sy = floor_to_int(floorf(cy));
             const int cxs = min(max(sx, -win_w), Lw - 1), cys = min(max(sy, -win_h), Lh - 1);
@@ -331,13 +346,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                 // the template's image rows first (they depend on the previous point only): bytes (xp0 & ~3) .. + 4 COLS of IROWS rows, a lane =
                 // (row of the round, 8-byte piece).  Then the J region the same way.
                 const int xp0 = (act ? ipx : 0) + pad_x, yp0 = (act ? ipy : 0) + pad_y;
-                const int rr = hl / PCS, pc = hl & (PCS - 1);
+                const int rr = hl / PCS, pc = hl - rr * PCS;
+                const bool stg = !SPARE || rr < RPR;
                 uint32_t offI = __umul24((unsigned)(yp0 + rr), (unsigned)pitch) + ((unsigned)xp0 & ~3u) + 8u * (unsigned)pc;
                 uint32_t* stI = ldsI + rr * IPITCH + 2 * pc;
                 u32x2 vi[IROWS / RPR];
                 // run-time windows: IROWS is the count for the largest window of the shape; rows past those the lane-items of THIS window
                 // read (the plane's slack below its bottom border covers exactly those) are replaced by the last such row
-                const int irows_need = PPW >= 4 ? NT + 1 : 8 * nblk + 1;
+                const int irows_need = COLF ? NT + 1 : 8 * nblk + 1;
 #pragma unroll
                 for (int k = 0; k < IROWS / RPR; ++k) {
                     if (WIN) { vi[k] = ldg<u32x2>(Ibase, offI); offI += (unsigned)RPR * (unsigned)pitch; }
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
 #pragma unroll
                     for (int k = 0; k < JR; ++k) { vj[k] = ldg<u32x2>(Jbase, off); off += (unsigned)RPR * (unsigned)pitch; }
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
+                    for (int i = 0; i < PRE_ITEMS; ++i) {
                         const uint32_t offD = __umul24((unsigned)(yp0 + ity[i]), (unsigned)dpitch) + 4u * (unsigned)(xp0 + itx[i]);
                         gbase_t rowD = Dbase;
 #pragma unroll
@@ -381,13 +397,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                         asm volatile("" :: "v"(f0), "v"(f1), "v"(f2), "v"(f3));
                     }
 #endif
+                    if (stg) {
 #pragma unroll
-                    for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = vj[k].x; st[RPR * k * lpd + 1] = vj[k].y; }
+                        for (int k = 0; k < JR; ++k) { st[RPR * k * lpd] = vj[k].x; st[RPR * k * lpd + 1] = vj[k].y; }
+                    }
                 } else {
                     stage_J_wide(rx0, ry0);
                 }
+                if (stg) {
 #pragma unroll
-                for (int k = 0; k < IROWS / RPR; ++k) { stI[RPR * k * IPITCH] = vi[k].x; stI[RPR * k * IPITCH + 1] = vi[k].y; }
+                    for (int k = 0; k < IROWS / RPR; ++k) { stI[RPR * k * IPITCH] = vi[k].x; stI[RPR * k * IPITCH + 1] = vi[k].y; }
+                }
             } else {
             uint32_t off = __umul24((unsigned)(ry0 + pad_y + sr), (unsigned)pitch) + (unsigned)(rx0 + pad_x + 4 * sc);
             const uint32_t step = (uint32_t)SR * (unsigned)pitch;
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
                         if constexpr (WIDE) { im.x = pI[r * IPITCH]; im.y = pI[r * IPITCH + 1]; }
                         else { im = ldg<u32x2>(rowI, offI); rowI += pitch; }
                         u32x2 dd;
-                        if constexpr (PRE) dd = ddv[i][r];
+                        if (PRE && i < PRE_ITEMS) dd = ddv[i < PRE_ITEMS ? i : 0][r];
                         else { dd = ldg<u32x2>(rowD, offD); rowD += dpitch; }
                         P = __builtin_amdgcn_perm(im.y, im.x, selI);
                         X = __builtin_amdgcn_perm(dd.y, dd.x, 0x05040100u);
@@ -832,6 +852,9 @@ static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
 {
     const int n8 = win_w * ((win_h + 7) / 8);
     if (win_w <= 16 && win_h <= 16) { ppw = LKG_PPW16; ni = LKG_PPW16 == 8 ? 2 : 1; }
+#ifndef LKG_NO_21_QUARTER
+    else if (win_w == 21 && win_h == 21) { ppw = 4; ni = 4; }      // configs[0] / configs[4]: 8-row items on a quarter wave, four points per wave
+#endif
     else if (n8 <= 32) { ppw = 2; ni = 1; }
     else if (n8 <= 64) { ppw = 2; ni = 2; }
     else { ppw = 1; ni = 2; }
@@ -849,19 +872,22 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     int ppw, ni;
     lk_group_shape(a.win_w, a.win_h, ppw, ni);
     const bool wide = LKG_WIDE != 0;
-    const int cols = ppw >= 4 ? 8 : 16, lanes = 64 / ppw, rpr = lanes / (cols / 2);
-    const int sr = wide ? rpr : lanes / cols, lpd = wide ? cols + 1 : ((a.win_w + 15) / 4) | 1;
+    const bool colf = ppw == 8 || (ppw == 4 && ni == 1);                     // as in the kernel
     const bool fixed = a.win_w == a.win_h && (a.win_w == 15 || a.win_w == 21 || a.win_w == 30);
-    const int rhs = (((fixed && ppw >= 4) ? a.win_h + 9 : ppw >= 4 ? 25 : a.win_h + 16) + sr - 1) / sr * sr;     // as in the kernel
+    const int cols = colf ? 8 : (fixed && ppw == 4) ? (((a.win_w + 2 * RM + 4 + 3) / 4 + 1) & ~1) : 16, lanes = 64 / ppw, rpr = lanes / (cols / 2);
+    const int sr = wide ? rpr : std::max(lanes / cols, 1), lpd = wide ? cols + 1 : ((a.win_w + 15) / 4) | 1;
+    const int rhs = (((fixed && colf) ? a.win_h + 9 : colf ? 25 : a.win_h + 16) + sr - 1) / sr * sr;     // as in the kernel
     dim3 grid((a.n_pts + ppw - 1) / ppw, n_pairs), block(64);
     // the groups' J regions; wide staging: behind them the template's staged image rows (IROWS x IPITCH dwords per point, as in the kernel)
-    const int irows_need = fixed ? (ppw >= 4 ? a.win_w + 1 : 8 * ((a.win_w + 7) / 8) + 1) : (ppw >= 4 ? 17 : 33);
+    const int irows_need = fixed ? (colf ? a.win_w + 1 : 8 * ((a.win_w + 7) / 8) + 1) : (colf ? 17 : 33);
     const int irows = (irows_need + rpr - 1) / rpr * rpr;
     const size_t shmem = ((size_t)ppw * rhs * lpd + (wide ? (size_t)ppw * irows * (cols + 1) : 0)) * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
     if (ppw == 8) {
         if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 8, 2>), grid, block, shmem, s, a);
         else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 8, 2>), grid, block, shmem, s, a);
+    } else if (ppw == 4 && ni == 4) {
+        DR3_LAUNCH(ev, (lk_trackg_kernel<21, 4, 4>), grid, block, shmem, s, a);
     } else if (ppw == 4) {
         if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 4, 1>), grid, block, shmem, s, a);
         else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 4, 1>), grid, block, shmem, s, a);

@@ -274,6 +274,8 @@ def lk_kernel_of(win_w, win_h):
     n8 = win_w * ((win_h + 7) // 8)
     if win_w <= 16 and win_h <= 16:
         ppw, ni, fixed = 8, 2, 15
+    elif win_w == 21 and win_h == 21:
+        ppw, ni, fixed = 4, 4, 21
     elif n8 <= 32:
         ppw, ni, fixed = 2, 1, -1
     elif n8 <= 64:

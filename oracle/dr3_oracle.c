@@ -175,12 +175,14 @@ enum { WSUM_A = 0, WSUM_B = 1, WSUM_E = 2 };
  * Windows up to 16 x 16 (e.g. the bench's 15x15): an EIGHTH of a wave -- 8 lanes, a lane owns the columns c and c + 8 (32 taps, one
  * exact integer sum), eight points per wave64.  Every
  * other window is cut into lane-items of 8 consecutive rows of a column, item q = (ty / 8) * win_w + tx on lane q % lanes: at most
- * 64 items (e.g. 8x32, 21x21) go to HALF a wave, two points per wave; more (e.g. the reference's 30x30) to a whole wave.
+ * 64 items (e.g. 8x32) go to HALF a wave, two points per wave -- 21x21 (63 items) to a QUARTER, four points per wave, four items per
+ * lane --; more (e.g. the reference's 30x30) to a whole wave.
  * DR3O_ORDER_WAVE64 follows whichever applies. */
 static int kernel_points_per_wave(int win_w, int win_h)
 {
     if (win_w > 32 || win_h > 32) return 1;             /* the plain form for windows beyond 32 x 32 (lk_track_big_kernel): always a whole wave */
     if (win_w <= 16 && win_h <= 16) return 8;           /* an EIGHTH of a wave: 8 lanes, lane = columns c and c + 8 */
+    if (win_w == 21 && win_h == 21) return 4;           /* configs[0] / configs[4]: 8-row items on a QUARTER wave (lk_trackg_kernel<21, 4, 4>) */
     if (win_w * ((win_h + 7) / 8) <= 64) return 2;
     return 1;
 }
@@ -189,7 +191,7 @@ static void wsum_init(wsum* s, int order, int kind, int win_w, int win_h)
 {
     const int ppw = kernel_points_per_wave(win_w, win_h);
     s->order = order; s->kind = kind; s->win_w = win_w;
-    s->blk_shift = ppw >= 4 ? 4 : 3;
+    s->blk_shift = (win_w <= 16 && win_h <= 16) ? 4 : 3;      /* whole columns (<= 16 rows) for the small windows, 8-row items otherwise */
     s->lanes = 64 / ppw;
     memset(s->lane, 0, sizeof(s->lane));
     memset(s->q, 0, sizeof(s->q));

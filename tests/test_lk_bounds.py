@@ -13,6 +13,8 @@ def group_shape(w, h):
     n8 = w * ((h + 7) // 8)
     if w <= 16 and h <= 16:
         return 8, 2
+    if (w, h) == (21, 21):
+        return 4, 4
     if n8 <= 32:
         return 2, 1
     if n8 <= 64:
@@ -22,15 +24,17 @@ def group_shape(w, h):
 
 def rows_read_below_origin(w, h):
     """(J rows from the region's first row, template image rows and derivative rows from the window's first row)"""
-    ppw, _ = group_shape(w, h)
+    ppw, ni = group_shape(w, h)
     fixed = w == h and w in (15, 21, 30)
-    cols, lanes = (8, 64 // ppw) if ppw >= 4 else (16, 64 // ppw)
+    colf = ppw == 8 or (ppw == 4 and ni == 1)                                      # whole-column lane-items
+    lanes = 64 // ppw
+    cols = 8 if colf else (((w + 2 * RM + 4 + 3) // 4 + 1) & ~1) if (fixed and ppw == 4) else 16
     rpr = lanes // (cols // 2)
-    nblk = 1 if ppw >= 4 else (h + 7) // 8
+    nblk = 1 if colf else (h + 7) // 8
     rh = h + 9
-    j_rows = -(-rh // rpr) * rpr if fixed else rh                                  # compile-time windows stage whole rounds
-    need = (h + 1 if fixed else 17) if ppw >= 4 else 8 * nblk + 1                  # rows the lane-items read (masked taps included)
-    i_rows = -(-need // rpr) * rpr if fixed else need                              # run-time windows stop at `need`
+    j_rows = -(-rh // rpr) * rpr + (1 if rpr * (cols // 2) != lanes else 0) if fixed else rh   # whole rounds (+ the spare lanes' row: loaded, not stored)
+    need = (h + 1 if fixed else 17) if colf else 8 * nblk + 1                      # rows the lane-items read (masked taps included)
+    i_rows = -(-need // rpr) * rpr + (1 if fixed and rpr * (cols // 2) != lanes else 0) if fixed else need   # run-time windows stop at `need`
     return j_rows, i_rows, need
 
 
@@ -49,7 +53,7 @@ def test_staging_rows_stay_inside_the_slack_behind_the_last_slot():
 
 
 def test_compile_time_shapes_match_the_launcher():
-    assert group_shape(15, 15) == (8, 2) and group_shape(21, 21) == (2, 2) and group_shape(30, 30) == (1, 2)
+    assert group_shape(15, 15) == (8, 2) and group_shape(21, 21) == (4, 4) and group_shape(30, 30) == (1, 2)
     assert rows_read_below_origin(15, 15) == (24, 16, 16)
-    assert rows_read_below_origin(21, 21) == (32, 28, 25)
+    assert rows_read_below_origin(21, 21) == (31, 28, 25)        # J: 10 rounds of 3 rows + the spare lane's row; I: 9 rounds + 1
     assert rows_read_below_origin(30, 30) == (40, 40, 33)

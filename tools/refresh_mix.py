@@ -17,7 +17,7 @@ def measured(tag):
 
 jobs = [("lk_trackg_kernelILi15ELi8ELi2E", "valu_mix.json", line["lk_kernel"]["kernel"].split("lk_trackg_kernel")[1], 4,
          line["lk_kernel"]["iterations"].get("executed_iteration_levels_per_wave") or line["lk_kernel"]["iterations"]["mean_iteration_levels_of_slowest_in_group"]),
-        ("lk_trackg_kernelILi21ELi2ELi2E", "valu_mix_configs0_21x21.json", "<21, 2, 2>", line["lk_other_windows"]["configs0_21x21_3_levels"]["levels"],
+        ("lk_trackg_kernelILi21ELi4ELi4E", "valu_mix_configs0_21x21.json", "<21, 4, 4>", line["lk_other_windows"]["configs0_21x21_3_levels"]["levels"],
          line["lk_other_windows"]["configs0_21x21_3_levels"].get("executed_iteration_levels_per_wave") or
          line["lk_other_windows"]["configs0_21x21_3_levels"]["mean_iteration_levels_of_slowest_in_group"]),
         ("lk_trackg_kernelILi30ELi1ELi2E", "valu_mix_ref_literals_30x30.json", "<30, 1, 2>", line["lk_real_frames"]["reference_literals_30x30"]["levels"],
