@@ -1013,8 +1013,8 @@ int dr3hip_batch_create(dr3hip_ctx* ctx, int w, int h, int win_w, int win_h, int
     if (max_level >= DR3HIP_MAX_LEVELS) return fail(ctx, DR3HIP_ERANGE, "batch_create: maxLevel %d >= %d", max_level, DR3HIP_MAX_LEVELS);
     if (win_w > DR3HIP_MAX_WIN || win_h > DR3HIP_MAX_WIN)
         return fail(ctx, DR3HIP_ERANGE, "batch_create: window %dx%d exceeds this build's limit (%d)", win_w, win_h, DR3HIP_MAX_WIN);
-    if (w <= win_w || h <= win_h)
-        return fail(ctx, DR3HIP_ERANGE, "batch_create: image %dx%d must be larger than the window %dx%d", w, h, win_w, win_h);
+    // an image no larger than the window is fine (cv::buildOpticalFlowPyramid keeps level 0 alone then; the border is REFLECT_101 repeated,
+    // which is what the border fill computes)
     // sides as at every entry point, and rows the tracker can address: it forms row offsets with 24-bit multiplies (__umul24), so the
     // derivative pitch 4 (w + 2 pad) + 16 must stay below 2^24 -- a frame up to DR3HIP_BATCH_MAX_W pixels wide
     if (!side_ok(w) || !side_ok(h) || w > DR3HIP_BATCH_MAX_W)

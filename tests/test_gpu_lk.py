@@ -400,3 +400,17 @@ def test_windows_beyond_32_run_on_the_plain_kernel(dr3, O, synth, ctx, win):
         assert np.array_equal(g_err.view(np.uint32), w_err.view(np.uint32)), (win, flags)
     ok = g_st == 1
     assert ok.sum() > 20
+
+
+@pytest.mark.parametrize("w,h,win", [(20, 18, (21, 21)), (16, 40, (15, 15)), (9, 9, (9, 9)), (30, 12, (30, 30)), (12, 12, (40, 40)), (64, 5, (7, 7))])
+def test_images_no_larger_than_the_window(dr3, O, synth, ctx, w, h, win):
+    """cv::calcOpticalFlowPyrLK accepts an image smaller than winSize (level 0 alone, border = REFLECT_101 repeated): so does the batch"""
+    A, B, _ = synth.frame_pair(w, h)
+    rng = np.random.default_rng(w * 1000 + h)
+    pts = np.stack([rng.uniform(-2, w + 2, 40), rng.uniform(-2, h + 2, 40)], 1).astype(np.float32)
+    for flags in (0, dr3.LK_GET_MIN_EIGENVALS):
+        pg, po = _params(dr3, O, win=win, max_level=3, max_iters=10, eps=0.02, flags=flags)
+        g_xy, g_st, g_err, g_L = ctx.calcOpticalFlowPyrLK(A, B, pts, None, pg)
+        w_xy, w_st, w_err, w_L = O.lk_track(A, B, pts, None, po, order=O.ORDER_WAVE64)
+        assert g_L == w_L
+        assert np.array_equal(g_st, w_st) and np.array_equal(g_xy.view(np.uint32), w_xy.view(np.uint32)) and np.array_equal(g_err.view(np.uint32), w_err.view(np.uint32)), (w, h, win, flags)

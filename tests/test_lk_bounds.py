@@ -42,7 +42,7 @@ def test_staging_rows_stay_inside_the_slack_behind_the_last_slot():
     for w, h in itertools.product(range(3, 33), repeat=2):
         pad_y = h + 6
         j_rows, i_rows, d_rows = rows_read_below_origin(w, h)
-        for lh in (h + 1, 47, 376):                                                # level heights: the smallest the ABI accepts, a coarse level, level 0
+        for lh in (4, h + 1, 47, 376):                                             # level heights: the smallest the ABI accepts (an image may be smaller than the window), a coarse level, level 0
             rows_available = lh + 2 * pad_y + SLACK_ROWS
             # the J region starts at most RM rows above the last image row (the staging centre is clamped to the level)
             last_j = (lh - 1 - RM) + pad_y + j_rows - 1
