@@ -18,8 +18,14 @@
  * and, for in-repo code, follows the reference source line by line in behaviour:
  *     utils::reduce_to_half / create_img_pyramid   src/utils.cpp:324-430
  *     utils::shi_tomasi_score                      src/utils.cpp:282-321
- * It is pinned only by analytic known-answer tests and an independent numpy restatement
- * (tests/test_oracle_*.py).
+ * Pinned BY THE REFERENCE'S OWN EXECUTED CODE (oracle/Makefile `ref`: the two functions of the path that compile without OpenCV,
+ * built from where they lie under /root/reference in the build container; outputs frozen as data fixtures):
+ *     halfSampleSSE2     src/utils.cpp:324-349      -> tests/golden/halfsample_sse2_ref.npz  (DR3O_HALF_SSE2 / _REF_X86)
+ *     utils::linspace    include/utils.hpp:36-46    -> tests/golden/linspace_ref.npz         (dr3o_linspace_f32, the feather ramps)
+ * Everything else -- every row whose arithmetic is OpenCV's -- stays PARITY UNPINNED by anything the reference holds: it is pinned by
+ * analytic known-answer tests, an independent numpy restatement and, for the one freedom that changes results (the f32 summation
+ * order of the tracker's window sums), by carrying all three orders that exist (scalar OpenCV, x86-64 SSE2 OpenCV, the HIP kernel) with
+ * the SSE2 one held against the real intrinsics (oracle/sse2_replay.c, tests/test_oracle_sse2.py).
  */
 #ifndef DR3_ORACLE_H
 #define DR3_ORACLE_H

@@ -1,7 +1,8 @@
 """ctypes front-end of the CPU oracle (oracle/dr3_oracle.c).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED (no reference fixtures exist; OpenCV absent) -- see dr3_oracle.h.
+PARITY UNPINNED for every row whose arithmetic is OpenCV's (absent here); the half-sampler's SSE2 path and linspace are pinned by
+the reference's own executed code -- see dr3_oracle.h.
 """
 import ctypes as C
 import os
