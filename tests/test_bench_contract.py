@@ -127,3 +127,18 @@ def test_strip_kernel_launch_shape_matches_the_recorded_traffic_shapes():
         strip = [v for k, v in prof.get("kernels", prof).items() if isinstance(v, dict) and "warp_tile_8uc3_kernel" in k]
         if strip:
             assert {"6094848", "7864320"} <= set(strip[0].get("shapes", {}).keys())
+
+
+def test_hd_workload_line_meets_the_bar_too():
+    """`python bench.py --workload hd` (configs[4]'s one-GPU share, the long form of `hd_share`): pair 0 of ITS stream -- the pair round 3
+    found over the bar against OpenCV's scalar order -- bit-exact in the kernel's order and within 1e-3 px of the x86-64 order on every
+    converged point"""
+    _, path = _newest()
+    f = os.path.join(os.path.dirname(path), "bench_hd_run.json")
+    if not os.path.exists(f) or os.path.basename(os.path.dirname(path)) < "r04":
+        pytest.skip("no hd line recorded beside the default one")
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    assert "1920x1080" in d["config"]["workload"] and d["verified_vs_oracle"] is True
+    ks = d["summation_order_agreement"]["kernel_vs_sse2"]
+    assert ks["status_equal"] and ks["same_path_within_tol"] and ks["converged_within_tol"], ks
+    assert 0 < d["roofline"]["frac"] <= 1.0
