@@ -237,6 +237,14 @@ def pmc_traffic(kernel_substr, batch, fname="pmc_traffic.json", grid_threads=Non
     return None, None
 
 
+def pyr_pass_traffic(batch, fname="pmc_traffic.json"):
+    """HBM bytes of one whole pyramid + gradient pass (all its launches) from the same committed PMC summary, or None"""
+    j, src = newest_profile(fname, kernel_source_hash(("pyr_kernels.hip", "warp_kernels.hip", "dr3hip_internal.h")))
+    if not j or j.get("batch", 256) != batch or not j.get("pyr_pass_hbm_bytes"):
+        return None
+    return j["pyr_pass_hbm_bytes"]
+
+
 def lk_valu_issue(lk_ms, waves, kernel):
     """The tracker against the VALU issue roofline of ITS OWN instruction mix.  gfx950 issues a wave64 VALU instruction in 2, 4
     or 8 clocks depending on the opcode (tools/ubench/valu_rate.hip, profiles/r02_lk/ubench_valu_rate*.txt), so the ceiling is
@@ -625,6 +633,7 @@ def main(argv=None):
         ach_l0 = b_l0 / (l0_ms * 1e-3) / 1e9
         ach_pass = b_pass / (pass_ms * 1e-3) / 1e9
         traffic_l0, traffic_src = pmc_traffic("pyr_level_kernel<true, true, 0>", B, "pmc_traffic.json" if args.workload == "kitti" else "pmc_traffic_hd.json")
+        traffic_pass = pyr_pass_traffic(B, "pmc_traffic.json" if args.workload == "kitti" else "pmc_traffic_hd.json")
         lk_kernel_name = lk_kernel_of(WIN, WIN)
         out = {
             "metric": "tracked_keypoints_per_sec",
@@ -666,7 +675,8 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": b_l0, "avg_launch_ms": l0_ms, "launches": n_l0},
             "roofline_pyr_grad_pass": {"kernel": "all %d level launches of one pyramid+gradient pass" % levels,
                                        "bound": "hbm", "achieved": ach_pass, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": ach_pass / HBM_PEAK_GBPS, "traffic": None,
+                                       "frac": ach_pass / HBM_PEAK_GBPS, "traffic": traffic_pass,
+                                       "frac_moved": None if not traffic_pass else traffic_pass / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes_per_pass": b_pass, "avg_pass_ms": pass_ms},
             "lk_kernel": {"kernel": lk_kernel_name, "avg_launch_ms": lk_ms,
                           "keypoints_per_sec_kernel_only": B * N_PTS / (lk_ms * 1e-3),

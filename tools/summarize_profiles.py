@@ -53,6 +53,24 @@ def per_kernel(path, counter, largest_grid_only=False):
     return acc
 
 
+def pyr_pass_bytes(fetch_csv, write_csv):
+    """HBM bytes of one pyramid + gradient pass: every (pyramid kernel, launch shape) the timed steps repeat (>= 3 dispatches), median
+    FETCH_SIZE x 2 + WRITE_SIZE each, summed; None if a pass is missing"""
+    tot = 0.0
+    for path, counter, mul in ((fetch_csv, "FETCH_SIZE", 2.0), (write_csv, "WRITE_SIZE", 1.0)):
+        if not os.path.exists(path):
+            return None
+        acc = {}
+        for row in csv.DictReader(open(path, newline="")):
+            if row["Counter_Name"] == counter and ("pyr_level_kernel" in row["Kernel_Name"] or "pad_reflect_kernel" in row["Kernel_Name"]):
+                acc.setdefault((row["Kernel_Name"], int(row["Grid_Size"])), []).append(float(row["Counter_Value"]))
+        rep = [statistics.median(v) for v in acc.values() if len(v) >= 3]
+        if not rep:
+            return None
+        tot += sum(rep) * 1024.0 * mul
+    return tot
+
+
 def main(src, dst):
     os.makedirs(dst, exist_ok=True)
     for name in ("hostinfo.txt",):
@@ -108,8 +126,13 @@ def main(src, dst):
             t["hbm_bytes"] = t["fetch_bytes"] + t["write_bytes"]
     json.dump(summary, open(os.path.join(dst, "pmc_fetch_write_summary.json"), "w"), indent=1)
     json.dump({"note": "bytes per launch, median over dispatches; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; "
-                       "bench.py --steps 2 --warmup 1 --no-cpu --no-warp (256 frames / 256 pairs x 2000 points per launch)",
-               "batch": 256, "source_hash": source_hash(TRAFFIC_HASH_FILES), "kernels": traffic}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+                       "bench.py --steps 2 --warmup 1 --no-cpu --no-warp (256 frames / 256 pairs x 2000 points per launch); "
+                       "pyr_pass_hbm_bytes = the launches of ONE pyramid + gradient pass of the timed step summed (every launch shape of the "
+                       "pyramid kernels that the steps repeat; the one-off full-batch build is left out)",
+               "batch": 256, "source_hash": source_hash(TRAFFIC_HASH_FILES), "kernels": traffic,
+               "pyr_pass_hbm_bytes": pyr_pass_bytes(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"),
+                                                    os.path.join(src, "pmc_write", "write_counter_collection.csv"))},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     # configs[4]'s per-GPU share (bench.py --workload hd: 64 pairs of 1920 x 1080 per launch)
     for name, dstname in (("prof_hd", "kernel_stats_hd.csv"), ("prof_all", "kernel_stats_all_legs.csv")):
         ks2 = os.path.join(src, name, "bench_kernel_stats.csv")
@@ -133,7 +156,10 @@ def main(src, dst):
     if hd:
         json.dump({"note": "bytes per launch of bench.py --workload hd (64 pairs of 1920 x 1080, 5000 points, 5 levels, 21 x 21), the largest "
                            "dispatch of each kernel; FETCH_SIZE doubled (gfx950)", "batch": 64, "source_hash": source_hash(TRAFFIC_HASH_FILES),
-                   "kernels": hd}, open(os.path.join(dst, "pmc_traffic_hd.json"), "w"), indent=1)
+                   "kernels": hd,
+                   "pyr_pass_hbm_bytes": pyr_pass_bytes(os.path.join(src, "pmc_hd_fetch", "fetch_counter_collection.csv"),
+                                                        os.path.join(src, "pmc_hd_write", "write_counter_collection.csv"))},
+                  open(os.path.join(dst, "pmc_traffic_hd.json"), "w"), indent=1)
     # warp / paste legs (tools/profile_warp.sh): same treatment, separate files
     ks = os.path.join(src, "prof_warp", "warp_kernel_stats.csv")
     if os.path.exists(ks):
