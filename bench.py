@@ -988,7 +988,7 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
         sync()
         ms, cnt = ctx.profile_read(dr3.PROF_LK)
         ctx.profile_enable(False)
-        ok = None
+        ok, orders = None, None
         if dist.rank == 0 and have_gpu:
             from oracle import oracle as O
             po = O.lk_params(**kw)
@@ -996,10 +996,16 @@ def lk_other_windows_leg(dist, ctx, dr3, synth, frames, sync, have_gpu):
             g_xy = d_next.download((NP, n, 2), np.float32)[0]; g_st = d_st.download((NP, n), np.uint8)[0]
             ok = bool(np.array_equal(g_xy.view(np.uint32), o[0].view(np.uint32)) and np.array_equal(g_st, o[1]) and
                       np.array_equal(d_err.download((NP, n), np.float32)[0].view(np.uint32), o[2].view(np.uint32)))
+            # the three summation orders on this configuration's pair 0 (north_star's 1e-3 px bar)
+            guess = pts.copy() if kw["flags"] & 4 else None
+            res = {od: O.lk_track(frames[0], frames[1], pts, guess, po, order=od, want_iters=True, opt=True) for od in (O.ORDER_WAVE64, O.ORDER_SSE2, O.ORDER_RASTER)}
+            g = (g_xy, g_st, None, res[O.ORDER_WAVE64][3], res[O.ORDER_WAVE64][4])
+            orders = {"kernel_vs_sse2": O.order_agreement(g, res[O.ORDER_SSE2], po, 1e-3), "kernel_vs_raster": O.order_agreement(g, res[O.ORDER_RASTER], po, 1e-3),
+                      "raster_vs_sse2": O.order_agreement(res[O.ORDER_RASTER], res[O.ORDER_SSE2], po, 1e-3)}
         k_ms = ms / max(cnt, 1)
         out[name] = {"kernel": kernel, "levels": b.levels, "pairs_per_launch": NP, "points_per_pair": n, "kernel_ms": k_ms,
                      "keypoints_per_sec_kernel_only": NP * n / (k_ms * 1e-3), "tracked_fraction": float(d_st.download((NP, n), np.uint8).mean()),
-                     "verified_vs_oracle": ok}
+                     "verified_vs_oracle": ok, "summation_order_agreement": orders}
         if have_gpu:                                       # iteration-levels per point and per lock-step group (what tools/lk_valu_mix.py weights by)
             d_it = ctx.alloc(NP * n * b.levels * 4)
             d_next.upload(P); b.track(NP, 0, d_prev, d_next, n, d_st, d_err, params, d_iters=d_it); sync()

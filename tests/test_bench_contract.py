@@ -54,7 +54,9 @@ def test_contract_fields_and_arithmetic():
         # north_star's 1e-3 px bar against the order the reference's x86-64 OpenCV executes, on the metric's configuration AND on
         # configs[4]'s pair (the one round 3 found over the bar against the scalar order): every converged point, no exception list
         assert d["pre_roll_steps"] == 256
-        for rec in (d["summation_order_agreement"], d["hd_share"]["summation_order_agreement"]):
+        recs = [d["summation_order_agreement"], d["hd_share"]["summation_order_agreement"]]
+        recs += [leg["summation_order_agreement"] for leg in d["lk_other_windows"].values() if leg.get("summation_order_agreement")]    # configs[0], literals
+        for rec in recs:
             ks = rec["kernel_vs_sse2"]
             assert ks["status_equal"] and ks["same_path_within_tol"] and ks["converged_within_tol"], ks
             assert ks["tracked_both"] - ks["clamped"] >= 0.99 * ks["tracked_both"]
