@@ -20,7 +20,7 @@ s = re.sub(r"frames resident: \d+ M keypoints/s in the committed run \([0-9.]+ m
 s = between(s, "| >= 50x the CPU `calcOpticalFlowPyrLK` throughput at 1 GPU |", "| >= 50x the CPU warp throughput |",
             "| >= 50x the CPU `calcOpticalFlowPyrLK` throughput at 1 GPU | **%s M keypoints/s** in the committed run (462 - 513 M box to box; %s M with two sequences per GPU on two "
             "streams) against **%.2f M** for the CPU port organised like an optimised library (\"port-opt\", §6 `cpu_baseline`: separable pyrDown, padded levels, the SSE2 window "
-            "loops of OpenCV's x86-64 build) on the box's %d host cores = **%.0fx** (1.6 - 2.2 M and 240 - 310x over the round's boxes); %.2f M on one thread; the readable port "
+            "loops of OpenCV's x86-64 build) on the box's %d host cores = **%.0fx** (1.6 - 2.2 M and 240 - 315x over the round's boxes); %.2f M on one thread; the readable port "
             "of round 3 reaches %.2f M on the same cores (%.0fx).  OpenCV itself is not in the image |\n"
             % (M(d["value"]), M(d["two_streams"]["keypoints_per_sec_this_gpu"]), c["value"] / 1e6, c["cores"], d["value"] / c["value"], c["single_thread_value"] / 1e6,
                c["readable_port"]["value"] / 1e6, d["value"] / c["readable_port"]["value"]))
