@@ -153,6 +153,8 @@ def _signatures():
         "dr3hip_batch_download": ([vp, ip, ip, ip, vp, ip], ip),
         "dr3hip_batch_pad_level0": ([vp, ip, ip], ip),
         "dr3hip_batch_build": ([vp, ip, ip, ip], ip),
+        "dr3hip_batch_build_ahead": ([vp, ip, ip, ip], ip),
+        "dr3hip_batch_join": ([vp], ip),
         "dr3hip_batch_track": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, P(LKParams)], ip),
         "dr3hip_batch_track_diag": ([vp, ip, ip, vp, vp, vp, vp, ip, vp, vp, vp, vp, P(LKParams)], ip),
         "dr3hip_lk_stats": ([vp, C.c_longlong, vp, vp, vp, ip, P(LKCounters)], ip),
@@ -631,6 +633,13 @@ class FrameBatch:
 
     def build(self, first, count, with_deriv=True):
         self.ctx._chk(lib().dr3hip_batch_build(self.h, first, count, int(with_deriv)))
+
+    def build_ahead(self, first, count, with_deriv=True):
+        """dr3hip_batch_build_ahead: levels >= 1 on the context's auxiliary stream, under what the context's stream does next"""
+        self.ctx._chk(lib().dr3hip_batch_build_ahead(self.h, first, count, int(with_deriv)))
+
+    def join(self):
+        self.ctx._chk(lib().dr3hip_batch_join(self.h))
 
     def detect(self, first, count, n_levels=3, cell_size=30, fast_threshold=20, detection_threshold=20.0, mode=HALF_REF_X86,
                d_xy=None, d_corners=None):

@@ -37,6 +37,12 @@ struct dr3hip_ctx {
     int prof_n[DR3HIP_PROF_SLOTS] = {0};
     std::vector<ProfEvent> pending;
     std::vector<hipEvent_t> ev_pool;      // recycled events: no hipEventCreate in the steady state
+    // dr3hip_batch_build_ahead: the launches of levels >= 1 of a pass run on an auxiliary stream, under whatever the context's stream
+    // does next (the tracker of OTHER slots); a consumer of those slots on the context's stream waits for their event first
+    struct Ahead { dr3hip_batch* b; int first, count; hipEvent_t done; };
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_fork = nullptr;
+    std::vector<Ahead> ahead;
     void* comm = nullptr;                 // ncclComm_t (RCCL), see "multi-GPU" below
     int comm_world = 0, comm_rank = -1;
     // streaming transfers (dr3hip_batch_upload_async / dr3hip_download_async): a copy stream per direction and a ring of chunk
@@ -183,6 +189,31 @@ static void prof_drain(dr3hip_ctx* ctx)
     ctx->pending.clear();
 }
 
+// ---- dr3hip_batch_build_ahead's bookkeeping ----------------------------------------------------------------------------
+// Makes the context's stream wait for the auxiliary work on slots [first, first + count) of batch b (count < 0: every pending entry
+// of b; b null: everything).  An entry the stream has been made to wait for is retired (its event goes back to the pool).
+static int ahead_join(dr3hip_ctx* ctx, const dr3hip_batch* b, int first, int count)
+{
+    for (size_t i = 0; i < ctx->ahead.size();) {
+        dr3hip_ctx::Ahead& e = ctx->ahead[i];
+        const bool hit = (!b || e.b == b) && (count < 0 || (first < e.first + e.count && e.first < first + count));
+        if (!hit) { ++i; continue; }
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e.done, 0));
+        ctx->ev_pool.push_back(e.done);
+        ctx->ahead.erase(ctx->ahead.begin() + (long)i);
+    }
+    return DR3HIP_OK;
+}
+static void ahead_release(dr3hip_ctx* ctx)
+{
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    for (auto& e : ctx->ahead) if (e.done) (void)hipEventDestroy(e.done);
+    ctx->ahead.clear();
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    ctx->aux = nullptr; ctx->aux_fork = nullptr;
+}
+
 // =================================================================================================
 extern "C" {
 
@@ -256,6 +287,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ahead_release(ctx);
     prof_drain(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
@@ -275,6 +307,7 @@ int dr3hip_sync(dr3hip_ctx* ctx)
     if (!ctx) return DR3HIP_EINVAL;
     DeviceGuard g(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) HIPCHK(ctx, hipStreamSynchronize(ctx->aux));          // work built ahead is part of what the caller waits for
     return DR3HIP_OK;
 }
 
@@ -287,6 +320,9 @@ int dr3hip_set_stream(dr3hip_ctx* ctx, void* hip_stream)
     // work already enqueued keeps its order: the old stream is drained (and its timing events read) before the switch.  A caller's
     // stream must outlive the switch away from it; if it did not (the drain fails), the switch still happens -- a context must not
     // stay stuck on a dead handle -- and the call reports the failure.
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);               // work built ahead belongs to the stream being left
+    for (auto& a : ctx->ahead) ctx->ev_pool.push_back(a.done);
+    ctx->ahead.clear();
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) (void)hipGetLastError();
     else prof_drain(ctx);
@@ -929,6 +965,7 @@ long long dr3hip_batch_bcast_slot(dr3hip_batch* b, int slot, int root, int with_
     if (!ctx->comm) return fail(ctx, DR3HIP_EINVAL, "batch_bcast_slot: no communicator (dr3hip_comm_init)");
     if (slot < 0 || slot >= b->capacity || root < 0 || root >= ctx->comm_world) return fail(ctx, DR3HIP_EINVAL, "batch_bcast_slot: bad slot/root");
     DeviceGuard g(ctx->device);
+    { const int rc = ahead_join(ctx, b, slot, 1); if (rc) return rc; }
     long long moved = 0;
     NCCLCHK(ctx, g_rccl.GroupStart());
     for (int l = 0; l < b->levels; ++l) {
@@ -1073,6 +1110,8 @@ void dr3hip_batch_destroy(dr3hip_batch* b)
 {
     if (!b) return;
     DeviceGuard g(b->ctx->device);
+    (void)ahead_join(b->ctx, b, 0, -1);                          // nothing of this batch stays in flight on the auxiliary stream
+    if (b->ctx->aux) (void)hipStreamSynchronize(b->ctx->aux);
     (void)hipStreamSynchronize(b->ctx->stream);
     for (int l = 0; l < DR3HIP_MAX_LEVELS; ++l) {
         if (b->img_base[l]) (void)hipFree(b->img_base[l]);
@@ -1278,6 +1317,7 @@ int dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void* 
         return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_download: bad arguments") : DR3HIP_EINVAL;
     dr3hip_ctx* ctx = b->ctx;
     DeviceGuard g(ctx->device);
+    { const int rc = ahead_join(ctx, b, slot, 1); if (rc) return rc; }
     const LevelDev& v = b->lv[level];
     if (what == 0)
         { const int rc2_ = copy2d_d2h(ctx, host, host_stride, v.img + (size_t)slot * v.step, v.pitch, v.w, v.h); if (rc2_) return rc2_; }
@@ -1287,14 +1327,21 @@ int dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void* 
     return DR3HIP_OK;
 }
 
-int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
+// ahead: the launches of levels >= 1 go to the context's auxiliary stream behind the level-0 launch (dr3hip_batch_build_ahead)
+static int batch_build_impl(dr3hip_batch* b, int first, int count, int with_deriv, bool ahead)
 {
     if (!b || first < 0 || count < 0 || first + count > b->capacity)
         return b ? fail(b->ctx, DR3HIP_EINVAL, "batch_build: slots [%d,%d) outside capacity %d", first, first + count, b->capacity) : DR3HIP_EINVAL;
     dr3hip_ctx* ctx = b->ctx;
     if (count == 0) return DR3HIP_OK;
     DeviceGuard g(ctx->device);
+    { const int rc = ahead_join(ctx, b, first, count); if (rc) return rc; }      // slots with auxiliary work pending are about to be rewritten
     const int L = b->levels - 1;
+    if (ahead && !ctx->aux) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    }
+    bool forked = false;
     // the launches of the pass: the level kernels (chunks of 32768 slots keep tiles * slots far below 2^31 blocks).  The physical
     // REFLECT_101 border of the levels this pass produces (read by the tracker only, never by the pyramid kernels) rides along: the
     // launch of level l >= 1 also writes level l's border (level 0 got its when the frame was uploaded, dr3hip_batch_upload).  Only
@@ -1311,8 +1358,17 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
         const int l = steps[i].level, s0 = steps[i].s0, n = count - s0 < 32768 ? count - s0 : 32768;
         LaunchEv ev;
         if (pe.which >= 0) { if (i == 0) ev.start = pe.e0; if (i + 1 == steps.size()) ev.stop = pe.e1; }
+        hipStream_t st = ctx->stream;
+        if (ahead && l != 0) {                                  // everything behind level 0: the auxiliary stream, once level 0 is through
+            if (!forked) {
+                HIPCHK(ctx, hipEventRecord(ctx->aux_fork, ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_fork, 0));
+                forked = true;
+            }
+            st = ctx->aux;
+        }
         if (l < 0) {
-            HIPCHK(ctx, launch_pad_reflect(&b->lv[L], 1, align_up(b->win_w + 16, 4), first + s0, n, ctx->stream, &ev));
+            HIPCHK(ctx, launch_pad_reflect(&b->lv[L], 1, align_up(b->win_w + 16, 4), first + s0, n, st, &ev));
             continue;
         }
         const bool down = l < L, deriv = with_deriv != 0;
@@ -1325,11 +1381,28 @@ int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv)
             if (!ev.start) ev.start = p0.e0;
             if (ev.stop) { ctx->ev_pool.push_back(p0.e1); p0.e1 = ev.stop; p0.own1 = false; } else ev.stop = p0.e1;
         }
-        HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, ctx->stream, &ev, l ? align_up(b->win_w + 16, 4) : 0));
+        HIPCHK(ctx, launch_pyr_level(a, n, down, deriv, l == 0, st, &ev, l ? align_up(b->win_w + 16, 4) : 0));
         prof_close(ctx, p0);
     }
     prof_close(ctx, pe);
+    if (forked) {                                               // consumers of these slots on the context's stream wait for this event
+        dr3hip_ctx::Ahead e; e.b = b; e.first = first; e.count = count; e.done = nullptr;
+        if (!ctx->ev_pool.empty()) { e.done = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else HIPCHK(ctx, hipEventCreate(&e.done));
+        HIPCHK(ctx, hipEventRecord(e.done, ctx->aux));
+        ctx->ahead.push_back(e);
+        if (ctx->ahead.size() > 8) { const int rc = ahead_join(ctx, nullptr, 0, -1); if (rc) return rc; }
+    }
     return DR3HIP_OK;
+}
+
+int dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv) { return batch_build_impl(b, first, count, with_deriv, false); }
+int dr3hip_batch_build_ahead(dr3hip_batch* b, int first, int count, int with_deriv) { return batch_build_impl(b, first, count, with_deriv, true); }
+int dr3hip_batch_join(dr3hip_batch* b)
+{
+    if (!b) return DR3HIP_EINVAL;
+    DeviceGuard g(b->ctx->device);
+    return ahead_join(b->ctx, b, 0, -1);
 }
 
 static int fill_lk_args(dr3hip_batch* b, const dr3hip_lk_params* p, LKArgs& a)
@@ -1379,6 +1452,8 @@ int dr3hip_batch_track_diag(dr3hip_batch* b, int n_pairs, int first_slot,
     if (L < 0) return L;
     if (n_pairs == 0 || n_pts == 0) return L;
     DeviceGuard g(ctx->device);
+    // slots built ahead: the tracker waits for those it reads (all of the batch's when the pairs come as device arrays)
+    { const int rc = d_prev_slot ? ahead_join(ctx, b, 0, -1) : ahead_join(ctx, b, first_slot, n_pairs + 1); if (rc) return rc; }
     ProfEvent pe; prof_open(ctx, DR3HIP_PROF_LK, pe);
     for (int p0 = 0; p0 < n_pairs; p0 += 32768) {              // grid.y limit
         LaunchEv ev;
@@ -1436,6 +1511,7 @@ int dr3hip_batch_align(dr3hip_batch* b, int n_pairs, int first_slot, const int* 
         return fail(ctx, DR3HIP_EINVAL, "batch_align: levels %d..%d not in the batch's pyramid (%d levels) or n_iter < 0", p->min_level, p->max_level, b->levels);
     if (n_pairs == 0) return DR3HIP_OK;
     DeviceGuard g(ctx->device);
+    { const int rc = ahead_join(ctx, b, 0, -1); if (rc) return rc; }
     const size_t per_pair = (size_t)((n_pts + 255) / 256) * 16 * 7 * 256 * sizeof(float);
     int rc;
     if ((rc = stage_reserve(ctx, 8, per_pair * (size_t)n_pairs + 256))) return rc;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DR3HIP_VERSION 102
+#define DR3HIP_VERSION 103
 #define DR3HIP_BATCH_MAX_W 4000000   /* widest frame of a dr3hip_batch: the tracker addresses rows of 4 (w + 2 pad) + 16 bytes with 24-bit pitches */
 
 /* error codes */
@@ -192,6 +192,15 @@ int  dr3hip_batch_download(dr3hip_batch* b, int slot, int level, int what, void*
 /* Enqueue pyramid (+ derivative when with_deriv) construction for slots first..first+count-1.
  * This is the "pyramid + gradient pass" graded against the HBM roofline. */
 int  dr3hip_batch_build(dr3hip_batch* b, int first, int count, int with_deriv);
+
+/* dr3hip_batch_build with the launches of levels >= 1 (25 % of the pass's bytes in a third of its time: three short, tail-bound
+ * launches) on an auxiliary stream of the context, behind the level-0 launch: they run UNDER whatever the context's stream is given
+ * next -- typically the tracker of other, already built slots (a ring of two slot groups: build group k + 1 ahead, track group k).
+ * Every later batch call that touches these slots (dr3hip_batch_track on pairs that read them, _build, _download, ...) makes the
+ * context's stream wait for them first, so results never depend on the overlap; dr3hip_batch_join does so explicitly for all of
+ * the batch's pending slots.  dr3hip_sync also waits for the auxiliary stream. */
+int  dr3hip_batch_build_ahead(dr3hip_batch* b, int first, int count, int with_deriv);
+int  dr3hip_batch_join(dr3hip_batch* b);
 
 /* Enqueue tracking of n_pairs frame pairs.  Pair i tracks slot prev_slot[i] -> next_slot[i]
  * (device int arrays; NULL means prev = first_slot + i, next = first_slot + i + 1).

@@ -92,6 +92,11 @@ class FrameBatch:
         ms, n = self.ctx.prof.get(PROF_PYR, (0.0, 0)); self.ctx.prof[PROF_PYR] = (ms + 0.1, n + 1)
         self.ctx.prof[PROF_PYR_L0] = self.ctx.prof[PROF_PYR]
 
+    def build_ahead(self, first, count, with_deriv=True):
+        self.build(first, count, with_deriv)
+
+    def join(self): pass
+
     def track(self, n_pairs, first_slot, d_prev, d_next, n_pts, d_st, d_err, params, *a, **k):
         t = STEP_SECONDS * (1 + 2 * self.ctx.rank)              # rank r takes (1 + 2r) x 10 ms: the job time is the last rank's
         time.sleep(t)

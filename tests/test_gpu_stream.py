@@ -130,3 +130,53 @@ def test_upload_of_the_next_batch_never_overtakes_the_tracker_of_this_one(dr3, s
     for a, c in out:
         ctx.host_free(a); ctx.host_free(c)
     b.close()
+
+
+def test_build_ahead_overlaps_the_tracker_without_changing_anything(dr3, O, synth, ctx):
+    """dr3hip_batch_build_ahead: a ring of two slot groups -- the levels >= 1 of group k + 1 are built on the auxiliary stream under the
+    tracker of group k.  Every consumer waits for the slots it reads, so positions, status and planes equal the serial build's; frames that
+    change between rounds must show up in the results (no stale level is ever read)."""
+    w, h, B = 320, 200, 6
+    frames, _ = synth.frame_stream(2 * (B + 1) + 3, w, h)
+    sets = [np.stack(frames[0:B + 1]), np.stack(frames[B + 1:2 * B + 2]), np.stack(frames[2:B + 3])]      # three different contents for a group
+    pts = synth.grid_points(w, h, 24)
+    n = len(pts)
+    P = np.ascontiguousarray(np.broadcast_to(pts[None], (B, n, 2)), np.float32)
+    pg = dr3.lk_params(win=(15, 15), max_level=3, max_iters=20, eps=0.01)
+    fb = dr3.FrameBatch(ctx, w, h, win=(15, 15), max_level=3, capacity=2 * (B + 1))
+    d_prev = ctx.to_device(P)
+    res = [(ctx.to_device(P), ctx.alloc(B * n), ctx.alloc(B * n * 4)) for _ in range(2)]
+    try:
+        def serial(content):
+            fb.upload(0, content); fb.build(0, B + 1, True)
+            fb.track(B, 0, d_prev, res[0][0], n, res[0][1], res[0][2], pg); ctx.sync()
+            return res[0][0].download((B, n, 2), np.float32).copy(), res[0][1].download((B, n), np.uint8).copy()
+        want = [serial(c) for c in sets]
+        # the ring: group g = slots g (B + 1) .. g (B + 1) + B
+        order = [0, 1, 2, 0, 2, 1, 1, 0]                                   # contents given to the groups, round by round
+        fb.upload(0, sets[order[0]]); fb.build(0, B + 1, True)
+        for r in range(len(order) - 1):
+            g, gn = r % 2, (r + 1) % 2
+            fb.upload(gn * (B + 1), sets[order[r + 1]])                    # new frames for the other group ...
+            fb.build_ahead(gn * (B + 1), B + 1, True)                      # ... level 0 now, levels 1.. under the tracker below
+            fb.track(B, g * (B + 1), d_prev, res[g][0], n, res[g][1], res[g][2], pg)
+            if r == 3:                                                     # a plane of the group being built ahead: the download waits for it
+                got = fb.download_image(gn * (B + 1) + 2, 2)
+                ref = O.pyr_down(O.pyr_down(sets[order[r + 1]][2]))
+                assert np.array_equal(got, ref)
+            ctx.sync()
+            xy, st = res[g][0].download((B, n, 2), np.float32), res[g][1].download((B, n), np.uint8)
+            assert np.array_equal(xy.view(np.uint32), want[order[r]][0].view(np.uint32)) and np.array_equal(st, want[order[r]][1]), r
+        fb.join()
+        for lvl in range(fb.levels):                                       # and the planes built ahead equal the oracle's pyramid
+            img = sets[order[-1]][1]
+            for _ in range(lvl):
+                img = O.pyr_down(img)
+            gl = ((len(order) - 1) % 2) * (B + 1) + 1
+            assert np.array_equal(fb.download_image(gl, lvl), img) and np.array_equal(fb.download_deriv(gl, lvl), O.scharr(img)), lvl
+    finally:
+        d_prev.free()
+        for t in res:
+            for d in t:
+                d.free()
+        fb.close()
