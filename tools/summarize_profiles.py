@@ -91,7 +91,9 @@ def main(src, dst):
     # same kernel trace, so that the live HIP-event figures can be compared like for like (tests/test_bench_contract.py).
     kt, bl = os.path.join(src, "prof_r1", "bench_kernel_trace.csv"), os.path.join(dst, "bench_line_under_rocprof.json")
     if os.path.exists(kt) and os.path.exists(bl):
-        steps = json.loads(open(bl).read())["steps"]
+        line = json.loads(open(bl).read())
+        steps = line["steps"]
+        after = (line.get("step_structure") or {}).get("launches_after_timed_region") or {}      # launches of the same kernels behind the timed region
         per = {}
         for row in csv.DictReader(open(kt, newline="")):
             per.setdefault(row["Kernel_Name"], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
@@ -99,7 +101,8 @@ def main(src, dst):
         for k, v in per.items():
             if "lk_track" in k or "pyr_level_kernel<true, true, 0>" in k:
                 v.sort()
-                last = [d for _, d in v[-steps:]]
+                skip = int(after.get("lk" if "lk_track" in k else "pyr_l0", 0))
+                last = [d for _, d in (v[-(steps + skip):-skip] if skip else v[-steps:])]
                 timed[k] = {"launches_in_run": len(v), "timed_launches": len(last), "mean_ms_timed": sum(last) / len(last) * 1e-6,
                             "mean_ms_all": sum(d for _, d in v) / len(v) * 1e-6}
         json.dump({"note": "rocprofv3 --kernel-trace of the bench run whose line is bench_line_under_rocprof.json: mean duration of the last "
