@@ -1338,7 +1338,14 @@ static int batch_build_impl(dr3hip_batch* b, int first, int count, int with_deri
     { const int rc = ahead_join(ctx, b, first, count); if (rc) return rc; }      // slots with auxiliary work pending are about to be rewritten
     const int L = b->levels - 1;
     if (ahead && !ctx->aux) {
+        // the LOWEST priority: the auxiliary launches fill what the stream's own kernels leave free and do not compete with them
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+#ifdef DR3_AUX_DEFAULT_PRIORITY
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+#else
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, least));
+#endif
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
     }
     bool forked = false;
