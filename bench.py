@@ -72,10 +72,22 @@ class Dist:
                 self.device = torch.device("cpu")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.pg = True
+            # barriers and the scalar reductions of the timing protocol go over a gloo group on the CPU: a barrier of the RCCL group is an
+            # all-reduce kernel plus a host wait (0.5 ms measured at world size 1), which would sit inside every timed region of N > 1
+            # runs and nowhere in the N = 1 run they are compared with
+            self.cpu_group = None
+            if backend == "nccl" and os.environ.get("DR3_BENCH_NCCL_BARRIER") != "1":
+                try:
+                    self.cpu_group = dist.new_group(backend="gloo")
+                except Exception:                                # noqa: BLE001 -- the RCCL group does the same, slower
+                    self.cpu_group = None
 
     def barrier(self):
         if self.pg:
-            self.dist.barrier()
+            if getattr(self, "cpu_group", None) is not None:
+                self.dist.barrier(group=self.cpu_group)
+            else:
+                self.dist.barrier()
 
     def bcast_intrinsics(self, values):
         """rank 0's (fx, fy, cx, cy, W, H) to every rank -- the path's only collective"""
@@ -103,19 +115,22 @@ class Dist:
         self.dist.all_gather(out, t)
         return [bytes(o.cpu().tolist()) for o in out]
 
-    def max_over_ranks(self, x):
+    def _reduce(self, x, op):
         if not self.pg:
             return float(x)
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        if getattr(self, "cpu_group", None) is not None:
+            t = self.torch.tensor([float(x)], dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=op, group=self.cpu_group)
+        else:
+            t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=op)
         return float(t.item())
 
+    def max_over_ranks(self, x):
+        return self._reduce(x, self.dist.ReduceOp.MAX) if self.pg else float(x)
+
     def sum_over_ranks(self, x):
-        if not self.pg:
-            return float(x)
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return self._reduce(x, self.dist.ReduceOp.SUM) if self.pg else float(x)
 
     def close(self):
         if self.pg:
