@@ -183,6 +183,7 @@ def _signatures():
         "dr3hip_stitch_compose": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
         "dr3hip_stitch_compose_dev": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, vp, ip], ip),
         "dr3hip_stitch_plan": ([vp, ip, ip, ip, vp, ip, ip, ip, vp, vp, ip, ip, C.c_float, C.c_float, C.c_float, P(ip)], ip),
+        "dr3hip_panorama_plan": ([vp, ip, ip, ip, ip, ip, vp, ip, ip, P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_bbox": ([vp, ip, ip, P(ip), P(ip), P(ip), P(ip)], ip),
         "dr3hip_panorama_ramp": ([ip, ip, ip, vp], ip),
         "dr3hip_panorama_add": ([vp, vp, ip, ip, ip, vp, ip, ip, ip, vp, ip], ip),
@@ -743,6 +744,22 @@ def stitch_plan(lw, lh, rw, rh, T, M, size, alpha=0.5, beta=0.5, gamma=0.0, lstr
     if rc != 0:
         raise Dr3HipError("dr3hip_stitch_plan failed: %d" % rc)
     return k.value
+
+
+def panorama_plan(w, h, canvas_size, M, istride=None, slab=None):
+    """which form the paste of a w x h image with the forward matrix M onto a canvas takes (dr3hip_panorama_plan): (kernel, coords, box)
+    -- kernel 2 = strips / 0 = direct, coords 0 .. 3 = the coordinate form over the box, box = (x0, y0, x1, y1) the launch evaluates;
+    the stride defaults to the 64-byte aligned pitch the host-buffer entry point stages with"""
+    cw, ch = canvas_size
+    k, c = C.c_int(), C.c_int()
+    box = (C.c_int * 4)()
+    st = istride if istride is not None else (3 * w + 63) // 64 * 64
+    y0, y1 = slab if slab is not None else (0, ch)
+    rc = lib().dr3hip_panorama_plan(None, int(w), int(h), int(st), int(cw), int(ch), _p(np.ascontiguousarray(np.asarray(M, np.float32).reshape(9))),
+                                    int(y0), int(y1), C.byref(k), C.byref(c), box)
+    if rc != 0:
+        raise Dr3HipError("dr3hip_panorama_plan failed: %d" % rc)
+    return k.value, c.value, tuple(box)
 
 
 def stitch_geometry(H, w, h):

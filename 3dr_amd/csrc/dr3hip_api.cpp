@@ -648,6 +648,8 @@ int dr3hip_normalize_points(dr3hip_ctx* ctx, const float* xy, int n, float* out_
 // ---- panorama paste -------------------------------------------------------------------------
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
                      const float M[9], int flags);      // defined with the warp entry points below
+static bool box_w_one_sign(const double M[9], int x0, int y0, int x1, int y1);
+static void plan_rect(WarpJobDev& j, int x0, int y0, int x1, int y1);
 
 int dr3hip_panorama_bbox(const float M[9], int w, int h, int* min_x, int* min_y, int* max_x, int* max_y)
 {
@@ -695,34 +697,21 @@ int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int
     return dr3hip_panorama_add_slab(ctx, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, feathering_width, 0, ch);
 }
 
-int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
-                             float* d_canvas, int cw, int ch, int cstride, const float M[9], int feathering_width,
-                             int slab_y0, int slab_y1)
+// the launch record of one paste without its ramp: box columns and rows, inverse map, and the coordinate form / strip plan of the box.
+// Returns the box's column count (max_x - min_x), or a negative code for a box the reference throws on.
+static int pano_add_args(const uint8_t* d_img, int w, int h, int istride, float* d_canvas, int cw, int ch, int cstride, const float M[9],
+                         int slab_y0, int slab_y1, PanoAddArgs& a, int& min_x, int& max_x)
 {
-    if (!ctx) return DR3HIP_EINVAL;
-    if (!d_img || !d_canvas || !M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || cstride < 16 * cw ||
-        slab_y0 < 0 || slab_y1 > ch || slab_y0 >= slab_y1)
-        return fail(ctx, DR3HIP_EINVAL, "panorama_add: bad arguments");
-    if ((((uintptr_t)d_canvas | (uintptr_t)cstride) & 15) != 0) return fail(ctx, DR3HIP_EINVAL, "panorama_add: canvas rows must be 16-byte aligned");
-    int min_x, min_y, max_x, max_y;
+    int min_y, max_y;
     dr3hip_panorama_bbox(M, w, h, &min_x, &min_y, &max_x, &max_y);
     const int n = max_x - min_x;
-    if (n < 2 || n > (1 << 24)) return fail(ctx, DR3HIP_EINVAL, "panorama_add: bounding box of %d columns (the reference throws below 2)", n);
-    std::vector<float> ramp((size_t)n);
-    if (dr3hip_panorama_ramp(min_x, max_x, feathering_width, ramp.data()) != n)
-        return fail(ctx, DR3HIP_EINVAL, "panorama_add: feathering width %d does not fit a %d-column box", feathering_width, n);
-    DeviceGuard g(ctx->device);
-    int rc;
-    if ((rc = stage_reserve(ctx, 6, sizeof(float) * (size_t)n))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[6].p, ramp.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                       // ramp is a local
+    if (n < 2 || n > (1 << 24)) return DR3HIP_EINVAL;
     WarpJobDev j;                                                         // the :192 warp: dst = the whole canvas
     make_job(j, d_img, w, h, istride, d_canvas, cw, ch, cstride, M, 0);
-    PanoAddArgs a;
     a.img = d_img; a.w = w; a.h = h; a.istride = istride;
     a.canvas = d_canvas; a.cw = cw; a.ch = ch; a.cstride = cstride;
     for (int i = 0; i < 9; ++i) a.M[i] = j.M[i];
-    a.bw0 = j.bw0; a.bw0_shift = j.bw0_shift; a.fast = j.fast;
+    a.bw0 = j.bw0; a.bw0_shift = j.bw0_shift;
     a.cx0 = min_x < 0 ? 0 : min_x; a.cx1 = max_x > cw ? cw : max_x; a.min_x = min_x;
     // The reference walks every canvas row of the box columns; rows whose samples are all border-0 change nothing
     // (:205-207).  A canvas pixel samples the image only if its source coordinate lies within 1 px of it, so the
@@ -738,7 +727,9 @@ int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h
             if (!(W > 1e-9) || !std::isfinite(Y)) ok = false;
             ylo = std::fmin(ylo, Y); yhi = std::fmax(yhi, Y);
         }
-        if (ok && j.fast) {                        // j.fast: W of one sign and bounded away from 0 over the whole canvas
+        // W of the inverse map of one sign and bounded away from 0 over the box columns (all rows): no canvas pixel of those columns
+        // reaches the image "through infinity"
+        if (ok && a.cx1 > a.cx0 && box_w_one_sign(j.M, a.cx0, 0, a.cx1, ch)) {
             const double lo = std::floor(ylo) - 2.0, hi = std::ceil(yhi) + 3.0;
             a.cy0 = lo < 0.0 ? 0 : (lo > ch ? ch : (int)lo);
             a.cy1 = hi > ch ? ch : (hi < 0.0 ? 0 : (int)hi);
@@ -747,6 +738,48 @@ int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h
     a.slab_y0 = slab_y0;                                                 // only rows [slab_y0, slab_y1) live in d_canvas
     if (a.cy0 < slab_y0) a.cy0 = slab_y0;
     if (a.cy1 > slab_y1) a.cy1 = slab_y1;
+    // the coordinate form the kernel may take is decided over the pixels it evaluates -- the box -- not over the whole canvas (a canvas
+    // of several images is wider than the +-8000 source pixels the fast forms cover, the box of one image is not)
+    plan_rect(j, a.cx0, a.cy0, a.cx1, a.cy1);
+    a.fast = j.fast; a.tile = j.tile; a.tile_lds = j.tile_lds; a.tile_guard = j.tile_guard;
+    a.ramp = nullptr;
+    return n;
+}
+
+int dr3hip_panorama_plan(const uint8_t* d_img, int w, int h, int istride, int cw, int ch, const float M[9], int slab_y0, int slab_y1,
+                         int* kernel, int* coords, int box[4])
+{
+    if (!M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || slab_y0 < 0 || slab_y1 > ch || slab_y0 >= slab_y1) return DR3HIP_EINVAL;
+    PanoAddArgs a; int min_x, max_x;
+    const int n = pano_add_args(d_img, w, h, istride, nullptr, cw, ch, 16 * cw, M, slab_y0, slab_y1, a, min_x, max_x);
+    if (n < 0) return n;
+    const bool empty = a.cx1 <= a.cx0 || a.cy1 <= a.cy0;
+    if (kernel) *kernel = (!empty && paste_takes_strips(a)) ? 2 : 0;
+    if (coords) *coords = a.fast;
+    if (box) { box[0] = a.cx0; box[1] = a.cy0; box[2] = a.cx1; box[3] = a.cy1; }
+    return DR3HIP_OK;
+}
+
+int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
+                             float* d_canvas, int cw, int ch, int cstride, const float M[9], int feathering_width,
+                             int slab_y0, int slab_y1)
+{
+    if (!ctx) return DR3HIP_EINVAL;
+    if (!d_img || !d_canvas || !M || w < 1 || h < 1 || cw < 1 || ch < 1 || istride < 3 * w || cstride < 16 * cw ||
+        slab_y0 < 0 || slab_y1 > ch || slab_y0 >= slab_y1)
+        return fail(ctx, DR3HIP_EINVAL, "panorama_add: bad arguments");
+    if ((((uintptr_t)d_canvas | (uintptr_t)cstride) & 15) != 0) return fail(ctx, DR3HIP_EINVAL, "panorama_add: canvas rows must be 16-byte aligned");
+    PanoAddArgs a; int min_x, max_x;
+    const int n = pano_add_args(d_img, w, h, istride, d_canvas, cw, ch, cstride, M, slab_y0, slab_y1, a, min_x, max_x);
+    if (n < 0) return fail(ctx, DR3HIP_EINVAL, "panorama_add: bounding box of %d columns (the reference throws below 2)", max_x - min_x);
+    std::vector<float> ramp((size_t)n);
+    if (dr3hip_panorama_ramp(min_x, max_x, feathering_width, ramp.data()) != n)
+        return fail(ctx, DR3HIP_EINVAL, "panorama_add: feathering width %d does not fit a %d-column box", feathering_width, n);
+    DeviceGuard g(ctx->device);
+    int rc;
+    if ((rc = stage_reserve(ctx, 6, sizeof(float) * (size_t)n))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[6].p, ramp.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                       // ramp is a local
     a.ramp = (const float*)ctx->stage[6].p;
     ProfEvent pe; prof_begin(ctx, DR3HIP_PROF_PANO_ADD, pe);
     HIPCHK(ctx, launch_panorama_add(a, ctx->stream));
@@ -1653,42 +1686,59 @@ static bool invert3x3(const double S[9], double T[9])
     return true;
 }
 
-// May the kernel use its guarded fast coordinate path (warp_kernels.hip, persp_tap_fast)?  W = M6 x + M7 y + M8
-// is linear, so its extremes over the destination are at the corners.  Conditions: source <= 8191 x 8191 and
-// all source coordinates within +-8000 px (13 extra fraction bits fit int32), every M finite, W of one sign with |W| >= 1e-6 max|W| and within
-// [1e-100, 1e100], and numerator operands bounded by 2^32 |W|min: then the FMA/Newton evaluation differs
-// from the exact f64 sequence by < 2^-52 * 2^32 * 2^18 = 1/4 unit of the 2-unit tie guard.
-static bool warp_fast_coords_ok(const double M[9], int sw, int sh, int dw, int dh)
+// the destination pixels a launch evaluates: columns [x0, x1), rows [y0, y1) -- the whole destination for a warp, the bounding box of
+// the pasted image for Panorama::add_img_to_canvas (whose destination is the whole canvas, of which it walks the box columns only)
+struct DstRect { int x0, y0, x1, y1; };
+static inline double rect_x(const DstRect& r, int a) { return (double)(a ? r.x1 - 1 : r.x0); }
+static inline double rect_y(const DstRect& r, int b) { return (double)(b ? r.y1 - 1 : r.y0); }
+static inline double rect_wmin(const double M[9], const DstRect& r)
 {
-    if (sw > 8191 || sh > 8191 || dw <= 0 || dh <= 0) return false;
+    double wmin = INFINITY;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmin = std::fmin(wmin, std::fabs(M[6] * rect_x(r, a) + M[7] * rect_y(r, b) + M[8]));
+    return wmin;
+}
+
+// W = M6 x + M7 y + M8 is linear, so its extremes over the rectangle are at the corners: of one sign there, |W| >= 1e-6 max|W| and
+// within [1e-100, 1e100] -- the rectangle then maps onto a convex quadrilateral whose corners bound every pixel
+static bool w_of_one_sign(const double M[9], const DstRect& r)
+{
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return false;
     for (int i = 0; i < 9; ++i) if (!std::isfinite(M[i])) return false;
-    const double xs[2] = {0.0, (double)(dw - 1)}, ys[2] = {0.0, (double)(dh - 1)};
     double wmin = INFINITY, wmax = 0.0; int pos = 0, neg = 0;
-    bool in_range = true;
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
-        const double w = M[6] * xs[a] + M[7] * ys[b] + M[8];
+        const double w = M[6] * rect_x(r, a) + M[7] * rect_y(r, b) + M[8];
         (w > 0 ? pos : neg)++;
         wmin = std::fmin(wmin, std::fabs(w)); wmax = std::fmax(wmax, std::fabs(w));
-        // the destination maps onto a convex quadrilateral (W of one sign): its corners bound every pixel
-        const double sx = (M[0] * xs[a] + M[1] * ys[b] + M[2]) / w, sy = (M[3] * xs[a] + M[4] * ys[b] + M[5]) / w;
-        if (!(std::fabs(sx) < 8000.0) || !(std::fabs(sy) < 8000.0)) in_range = false;
     }
-    if (!in_range) return false;
     if (pos != 4 && neg != 4) return false;
-    if (!(wmin >= 1e-100) || !(wmax <= 1e100) || wmin < 1e-6 * wmax) return false;
-    const double bx = std::fabs(M[0]) * dw + std::fabs(M[1]) * dh + std::fabs(M[2]);
-    const double by = std::fabs(M[3]) * dw + std::fabs(M[4]) * dh + std::fabs(M[5]);
+    return wmin >= 1e-100 && wmax <= 1e100 && !(wmin < 1e-6 * wmax);
+}
+
+// May the kernel use its guarded fast coordinate path (warp_kernels.hip, persp_tap_fast)?  Conditions: source <= 8191 x 8191 and
+// all source coordinates of the rectangle within +-8000 px (13 extra fraction bits fit int32), every M finite, W of one sign
+// (w_of_one_sign), and numerator operands bounded by 2^32 |W|min: then the FMA/Newton evaluation differs
+// from the exact f64 sequence by < 2^-52 * 2^32 * 2^18 = 1/4 unit of the 2-unit tie guard.
+static bool warp_fast_coords_ok(const double M[9], int sw, int sh, const DstRect& r)
+{
+    if (sw > 8191 || sh > 8191 || !w_of_one_sign(M, r)) return false;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        const double x = rect_x(r, a), y = rect_y(r, b), w = M[6] * x + M[7] * y + M[8];
+        const double sx = (M[0] * x + M[1] * y + M[2]) / w, sy = (M[3] * x + M[4] * y + M[5]) / w;
+        if (!(std::fabs(sx) < 8000.0) || !(std::fabs(sy) < 8000.0)) return false;
+    }
+    const double wmin = rect_wmin(M, r);
+    const double ax = std::fmax(std::fabs((double)r.x0), std::fabs((double)r.x1)), ay = std::fmax(std::fabs((double)r.y0), std::fabs((double)r.y1));
+    const double bx = std::fabs(M[0]) * ax + std::fabs(M[1]) * ay + std::fabs(M[2]);
+    const double by = std::fabs(M[3]) * ax + std::fabs(M[4]) * ay + std::fabs(M[5]);
     return bx < 4294967296.0 * wmin && by < 4294967296.0 * wmin;
 }
 
 // May the 4-pixel lanes derive pixels 1..3 from pixel 0 in f32 (warp_kernels.hip, persp_taps4_delta)?  On top of the conditions
 // above: q = M6 / W at most 1.2e-4 in magnitude and the source moves by at most 2 px per destination pixel along x, over the
-// whole destination (both are largest where |W| is smallest; source coordinates are bounded by 8000 px there already).
-static bool warp_delta_coords_ok(const double M[9], int dw, int dh)
+// whole rectangle (both are largest where |W| is smallest; source coordinates are bounded by 8000 px there already).
+static bool warp_delta_coords_ok(const double M[9], const DstRect& r)
 {
-    double wmin = INFINITY;
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
-        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double wmin = rect_wmin(M, r);
     const double q = std::fabs(M[6]) / wmin;
     const double dxdx = (std::fabs(M[0]) / wmin) + q * 8000.0, dydx = (std::fabs(M[3]) / wmin) + q * 8000.0;
     return q <= 1.2e-4 && dxdx <= 2.0 && dydx <= 2.0;
@@ -1696,34 +1746,39 @@ static bool warp_delta_coords_ok(const double M[9], int dw, int dh)
 
 // May the tile kernel derive the 16 pixels of a lane's destination column from ONE f64 anchor at its centre (warp_kernels.hip,
 // warp_tile_8uc3_kernel)?  On top of warp_fast_coords_ok: |p| <= 2e-4 (p = M7 / W) and the source moves by at most 2 px per
-// destination pixel along y, over the whole destination (both largest where |W| is smallest; source coordinates are bounded by
+// destination pixel along y, over the whole rectangle (both largest where |W| is smallest; source coordinates are bounded by
 // 8000 px there already).  The kernel's error budget is written for exactly these bounds.
-static bool tile_delta_coords_ok(const double M[9], int dw, int dh)
+static bool tile_delta_coords_ok(const double M[9], const DstRect& r)
 {
-    double wmin = INFINITY;
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
-        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double wmin = rect_wmin(M, r);
     const double p = std::fabs(M[7]) / wmin;
     const double dxdy = std::fabs(M[1]) / wmin + p * 8000.0, dydy = std::fabs(M[4]) / wmin + p * 8000.0;
     return p <= 2e-4 && dxdy <= 2.0 && dydy <= 2.0;
 }
 
+// 0: OpenCV's own f64 sequence per pixel; 1: the guarded fast coordinates; 2: + pixels 1..3 of a 4-pixel lane from pixel 0; 3: + one
+// anchor per strip column (WarpJobDev::fast)
+static int coords_level(const double M[9], int sw, int sh, const DstRect& r)
+{
+    return warp_fast_coords_ok(M, sw, sh, r) ? (warp_delta_coords_ok(M, r) ? (tile_delta_coords_ok(M, r) ? 3 : 2) : 1) : 0;
+}
+
 // May an 8UC3 job run on the LDS-staged strip kernel (warp_tile_8uc3_kernel), and how much LDS does a wave's 64 x 16 strip need?
 // Rows 16-byte aligned, 32-bit offsets, a power-of-two block split, W of one sign (a strip then maps onto a convex quadrilateral)
 // and a nearly affine map (fast == 3).  The LDS figure is an ESTIMATE: the source boxes (as the kernel forms them: corner taps,
-// one pixel of margin, rows cut to multiples of four pixels) of nine strips -- the destination's corners, edge centres and
+// one pixel of margin, rows cut to multiples of four pixels) of nine strips -- the rectangle's corners, edge centres and
 // centre -- plus one row and one chunk of slack; the box of a projective map grows monotonically towards one side, so this is its
 // maximum in practice, and a strip that does need more takes the kernel's slow way out (correct, not timed).  Returns 0 when the
-// job cannot run there.
-static int tile_kernel_lds(const WarpJobDev& j, const double M[9])
+// job cannot run there.  The strips are those the kernel cuts: 64 x 16 pixels from the rectangle's origin.
+static int tile_kernel_lds(const WarpJobDev& j, const double M[9], const DstRect& r)
 {
     if (j.fast != 3 || j.bw0_shift < 0) return 0;
     if ((((uintptr_t)j.src | (uintptr_t)j.sstride) & 15) || j.sstride >= (1 << 24) || j.sh >= (1 << 24) || (long long)j.sstride * j.sh >= (1LL << 31)) return 0;
-    const int tiles_x = (j.dw + kWarpTileW - 1) / kWarpTileW, strips_y = (j.dh + kWarpStripRows - 1) / kWarpStripRows;
+    const int tiles_x = (r.x1 - r.x0 + kWarpTileW - 1) / kWarpTileW, strips_y = (r.y1 - r.y0 + kWarpStripRows - 1) / kWarpStripRows;
     long long worst = 0;
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
         const int tx = a == 0 ? 0 : a == 1 ? tiles_x / 2 : tiles_x - 1, sy = b == 0 ? 0 : b == 1 ? strips_y / 2 : strips_y - 1;
-        const int xa = tx * kWarpTileW, xb = std::min(xa + kWarpTileW, j.dw) - 1, ya = sy * kWarpStripRows, yb = std::min(ya + kWarpStripRows, j.dh) - 1;
+        const int xa = r.x0 + tx * kWarpTileW, xb = std::min(xa + kWarpTileW, r.x1) - 1, ya = r.y0 + sy * kWarpStripRows, yb = std::min(ya + kWarpStripRows, r.y1) - 1;
         long long x_lo = LLONG_MAX, x_hi = LLONG_MIN, y_lo = LLONG_MAX, y_hi = LLONG_MIN;
         for (int c = 0; c < 4; ++c) {
             const double x = (c & 1) ? xb : xa, y = (c & 2) ? yb : ya, w = M[6] * x + M[7] * y + M[8];
@@ -1742,16 +1797,26 @@ static int tile_kernel_lds(const WarpJobDev& j, const double M[9])
 // T = 7.5 rows x the largest source step per destination row, so they carry the rounding of the step (1 ulp of T), of three fused
 // multiply-adds (half an ulp of T each), the dropped cubic term T (7.5 p)^3 and the conversion to an integer (0.5).  Guard 1 if that
 // stays under 0.95, else 2 (tile_delta_coords_ok bounds it by 1.75).
-static int tile_kernel_guard(const double M[9], int dw, int dh)
+static int tile_kernel_guard(const double M[9], const DstRect& r)
 {
-    double wmin = INFINITY;
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
-        wmin = std::fmin(wmin, std::fabs(M[6] * (a ? dw - 1 : 0) + M[7] * (b ? dh - 1 : 0) + M[8]));
+    const double wmin = rect_wmin(M, r);
     const double p = std::fabs(M[7]) / wmin;
     const double step = std::fmax(std::fabs(M[1]) / wmin + p * 8000.0, std::fabs(M[4]) / wmin + p * 8000.0);
     const double T = 7.5 * step * 262144.0, e = 7.5 * p;
     const double err = 0.5 + 2.5 * T / 16777216.0 + T * e * e * e;
     return err < 0.95 ? 1 : 2;
+}
+
+static bool box_w_one_sign(const double M[9], int x0, int y0, int x1, int y1) { const DstRect r = {x0, y0, x1, y1}; return w_of_one_sign(M, r); }
+
+// the coordinate form / strip plan of a job whose launch evaluates the pixels [x0, x1) x [y0, y1) of its destination only
+static void plan_rect(WarpJobDev& j, int x0, int y0, int x1, int y1)
+{
+    const DstRect r = {x0, y0, x1, y1};
+    j.fast = (x1 > x0 && y1 > y0) ? coords_level(j.M, j.sw, j.sh, r) : 0;
+    j.tile_lds = (x1 > x0 && y1 > y0) ? tile_kernel_lds(j, j.M, r) : 0;
+    j.tile_guard = j.tile_lds ? tile_kernel_guard(j.M, r) : 2;
+    j.tile = j.tile_lds ? 2 : 0;
 }
 
 static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride, void* dst, int dw, int dh, int dstride,
@@ -1769,9 +1834,10 @@ static void make_job(WarpJobDev& j, const void* src, int sw, int sh, int sstride
     j.bw0_shift = -1;
     if (j.bw0 >= dw) j.bw0_shift = 31;                                    // x0 == 0 for every x
     else if (j.bw0 >= 64 && (j.bw0 & (j.bw0 - 1)) == 0) j.bw0_shift = __builtin_ctz((unsigned)j.bw0);
-    j.fast = warp_fast_coords_ok(Md, sw, sh, dw, dh) ? (warp_delta_coords_ok(Md, dw, dh) ? (tile_delta_coords_ok(Md, dw, dh) ? 3 : 2) : 1) : 0;
-    j.tile_lds = tile_kernel_lds(j, Md);
-    j.tile_guard = j.tile_lds ? tile_kernel_guard(Md, dw, dh) : 2;
+    const DstRect whole = {0, 0, dw, dh};
+    j.fast = (dw > 0 && dh > 0) ? coords_level(Md, sw, sh, whole) : 0;
+    j.tile_lds = tile_kernel_lds(j, Md, whole);
+    j.tile_guard = j.tile_lds ? tile_kernel_guard(Md, whole) : 2;
     j.tile = j.tile_lds ? 2 : 0;
 }
 

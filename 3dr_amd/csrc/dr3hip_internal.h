@@ -88,7 +88,8 @@ struct StitchArgs {        // fused Stitch compose (src/stitch.cpp:72-80): job[0
 struct PanoAddArgs {       // fused Panorama::add_img_to_canvas (src/panorama.cpp:178-212)
     const uint8_t* img; int w, h, istride;        // 8UC3 source image
     float* canvas;      int cw, ch, cstride;      // 32FC4 weighted canvas (read-modify-write)
-    double M[9];        int bw0, bw0_shift, fast; // inverse map + WarpPerspectiveInvoker block split, as WarpJobDev
+    double M[9];        int bw0, bw0_shift, fast; // inverse map + WarpPerspectiveInvoker block split, as WarpJobDev (fast: over the box)
+    int tile, tile_lds, tile_guard;               // the strip plan of the box, as WarpJobDev (paste_strip_kernel)
     int cx0, cx1;                                 // canvas columns [cx0, cx1) = [min_x, max_x) clipped to the canvas
     int cy0, cy1;                                 // canvas rows that can receive a non-zero sample (host bound; all rows if unsure)
     int slab_y0;                                  // canvas row that `canvas` points at (0 unless a GPU owns a slab of rows)
@@ -208,6 +209,7 @@ hipError_t launch_sparse_align(const AlignArgs& a, int n_pairs, hipStream_t s);
 bool stitch_takes_strips(const StitchArgs& a);      // host only: would launch_stitch_compose run the strip form on these records?
 hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s);
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s);
+bool paste_takes_strips(const PanoAddArgs& a);       // host only: would launch_panorama_add run the strip form on this record?
 hipError_t launch_panorama_normalize(const PanoNormArgs& a, hipStream_t s);
 
 // geometry helpers shared by host and launchers

@@ -586,8 +586,7 @@ __device__ __forceinline__ uint32_t vgpr_const(uint32_t c) { uint32_t r; asm vol
 // One pixel on (or next to) a rounding tie: the guarded f64 evaluation of the direct kernel (reciprocal + Newton step, 13 extra
 // fraction bits of its own) and, where that one cannot decide either, OpenCV's own sequence.  Taps from the staged box when they
 // are inside it (a pixel that sits on a tie may round to the column or row next to the box), else from the image: [B G R 0]
-__device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M, int bw0_shift, const TileRegion& g, uint32_t lds0,
-                                                    gcu8 __restrict__ src, int sw, int sh, int sstride, int x, int y)
+__device__ __forceinline__ Tap tile_redo_tap(const double* __restrict__ M, int bw0_shift, int x, int y)
 {
     const int x0 = (x >> bw0_shift) << bw0_shift;
     const PerspBase pb0 = persp_base(M, x0, y);
@@ -595,6 +594,12 @@ __device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M
     PerspFast f; f.X0s = pb0.X0 * S; f.Y0s = pb0.Y0 * S; f.M0s = M[0] * S; f.M3s = M[3] * S;
     Tap e;
     if (!persp_tap_fast(M, pb0, f, (double)(x - x0), e)) e = persp_tap(M, pb0, (double)(x - x0));
+    return e;
+}
+__device__ __forceinline__ uint32_t tile_redo_pixel(const double* __restrict__ M, int bw0_shift, const TileRegion& g, uint32_t lds0,
+                                                    gcu8 __restrict__ src, int sw, int sh, int sstride, int x, int y)
+{
+    const Tap e = tile_redo_tap(M, bw0_shift, x, y);
     const int rx = e.sx - g.ox, ry = e.sy - g.oy;
     uint32_t aB, aG, aR;
     if (rx >= 0 && rx + 1 < 4 * g.cpr && ry >= 0 && ry + 1 < g.rows) {
@@ -689,16 +694,73 @@ __device__ __forceinline__ void stitch_fallback_8uc3(const WarpJobDev& jr, const
     }
 }
 
-// One 64 x 64 tile (four strips, one per wave) of one job.  STITCH: jb is the RIGHT image's job of a fused stitch, jl the left image's
+// ---- the fused paste on strips (reference src/panorama.cpp:178-212; the direct form and its semantics: panorama_add_kernel below) ------
+// The strip machinery evaluates only the box of the pasted image (columns [x0, dw), rows [y0, dh) of the canvas, dw / dh in the job
+// record); a pixel is the 32FC4 warp's f32 4-term sum of its taps times the feather ramp of its column, added to the canvas unless its
+// scaled B, G and R are all exactly 0.
+struct PasteStrip {
+    float* canvas; int cstride, slab_y0;       // `canvas` addresses canvas row slab_y0
+    const float* ramp; int min_x;              // ramp[x - min_x]
+    int x0, y0;                                // the box's first column / row: origin of the strips
+};
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// (B, G, R) of one pasted pixel from the BGRx dwords of its taps: v = tl w0 + tr w1 + bl w2 + br w3 in that order, no contraction, times r
+__device__ __forceinline__ void paste_px_bgrx(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, int fx, int fy, float r, float o[3])
+{
+    float w[4]; weights_32f(fx, fy, w);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v0 = (float)((tl >> (8 * c)) & 0xffu), v1 = (float)((tr >> (8 * c)) & 0xffu);
+        const float v2 = (float)((bl >> (8 * c)) & 0xffu), v3 = (float)((br >> (8 * c)) & 0xffu);
+        o[c] = (v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]) * r;
+    }
+}
+// one pasted pixel by per-tap checked loads (border 0) and the read-modify-write: the strip form's way for pixels on a rounding tie
+// and for strips it cannot take
+__device__ __forceinline__ void paste_px_checked(gcu8 __restrict__ src, int sw, int sh, int sstride, const Tap e, const PasteStrip& ps, int x, int y)
+{
+    if (e.sx >= sw || e.sx + 1 < 0 || e.sy >= sh || e.sy + 1 < 0) return;
+    float w[4]; weights_32f(e.fx, e.fy, w);
+    const float r = ps.ramp[x - ps.min_x];
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t q = quad_checked(src, sw, sh, sstride, e.sx, e.sy, 3, c);
+        const float v0 = (float)(q & 0xffu), v1 = (float)((q >> 8) & 0xffu), v2 = (float)((q >> 16) & 0xffu), v3 = (float)(q >> 24);
+        o[c] = (v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]) * r;
+    }
+    if (o[0] == 0.f && o[1] == 0.f && o[2] == 0.f) return;
+    DR3_G f32x4_t* cp = reinterpret_cast<DR3_G f32x4_t*>((gu8)reinterpret_cast<uint8_t*>(ps.canvas) + (long long)(y - ps.slab_y0) * ps.cstride) + x;
+    f32x4_t c4 = *cp;
+    c4.x += o[0]; c4.y += o[1]; c4.z += o[2]; c4.w += r;
+    *cp = c4;
+}
+__device__ __forceinline__ void paste_fallback(const WarpJobDev& jb, const PasteStrip& ps, int x, int y0)
+{
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = jb.M[i];
+    if (x >= jb.dw) return;
+    const int x0 = block_origin(x, jb.bw0, jb.bw0_shift);
+    for (int j = 0; j < kWaveRows; ++j) {
+        const int y = y0 + j;
+        if (y >= jb.dh) return;
+        paste_px_checked((gcu8)jb.src, jb.sw, jb.sh, jb.sstride, persp_tap(M, persp_base(M, x0, y), (double)(x - x0)), ps, x, y);
+    }
+}
+
+// One 64 x 64 tile (four strips, one per wave) of one job.  MODE 0: the 8UC3 warp.  MODE 2 (PASTE): the fused paste above.  MODE 1 (STITCH): jb is the RIGHT image's job of a fused stitch, jl the left image's
 // (exact fallback), sl its translation form: the strip's pixels are addWeighted(left, right) instead of the warped right image.
 // Every job: fast == 3, rows 16-byte aligned, power-of-two block split, strips inside the launch's LDS slice
 // (WarpJobDev::tile == 2, tile_kernel_lds on the host).  LDS of wave w: [slice: lds_bytes][tie list: 256 B] at w (lds_bytes + 256).
-template <bool STITCH>
-__device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const WarpJobDev* jl, const StitchLeft* slp, int t, int tiles_x, int lds_bytes, uint8_t* s_dyn,
+template <int MODE>
+__device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const WarpJobDev* jl, const StitchLeft* slp, const PasteStrip* pp, int t, int tiles_x, int lds_bytes, uint8_t* s_dyn,
                                                 int wv, int lds_slot)     // wv: the wave's strip of the tile; lds_slot: its slice of the block's LDS
 {
+    constexpr bool STITCH = MODE == 1, PASTE = MODE == 2;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int tx0 = tx * kTileW, ty0 = ty * kTileH;
+    const int tx0 = (PASTE ? pp->x0 : 0) + tx * kTileW, ty0 = (PASTE ? pp->y0 : 0) + ty * kTileH;
     const int dw = jb.dw, dh = jb.dh;
     const int lane = threadIdx.x;
     const int x = tx0 + lane, y0 = ty0 + kWaveRows * wv;
@@ -713,7 +775,7 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
     const bool dst_aligned = ((reinterpret_cast<uintptr_t>(jb.dst) | (uintptr_t)dstride) & 3) == 0;
     const bool src16 = ((reinterpret_cast<uintptr_t>(jb.src) | (uintptr_t)sstride) & 15) == 0 &&
                        sstride < (1 << 24) && sh < (1 << 24) && (long long)sstride * sh < (1LL << 31);
-    if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else tile_fallback_8uc3(jb, x, y0); return; }
+    if (!(src16 && bw0_shift >= 0 && jb.fast == 3)) { if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else if (PASTE) paste_fallback(jb, *pp, x, y0); else tile_fallback_8uc3(jb, x, y0); return; }
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_dyn + (uint32_t)lds_slot * (uint32_t)(lds_bytes + 256);    // this wave's slice (LDS byte address)
     const uint32_t list0 = lds0 + (uint32_t)lds_bytes;
 
@@ -764,12 +826,28 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
         g.pitch = g.cpr * 16;
     }
     if (!(g.cpr >= 1 && g.cpr <= 64 && g.rows >= 1 && g.rows <= 4096 && g.rows * g.pitch <= lds_bytes && g.ox > -16384 && g.oy > -16384)) {
-        if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else tile_fallback_8uc3(jb, x, y0);
+        if (STITCH) stitch_fallback_8uc3(jb, *jl, *slp, x, y0); else if (PASTE) paste_fallback(jb, *pp, x, y0); else tile_fallback_8uc3(jb, x, y0);
         return;
     }
     // a box that lies outside the image by more than the pixel a rounding tie can move a tap: every pixel of the strip is the border
     // constant -- nothing is staged, no coordinate is evaluated (the canvas of a stitch is mostly such strips for one image or the other)
     const bool r_any = !(g.ox - 2 >= sw || g.ox + 4 * g.cpr + 2 <= 0 || g.oy - 2 >= sh || g.oy + g.rows + 2 <= 0);
+    if (PASTE && !r_any) return;                                             // every scaled sample is exactly 0: nothing is added
+    const int xc = min(x, dw - 1);                                          // PASTE: a lane behind the box's last column shadows it (loads only)
+    float pr = 0.f;
+    // PASTE: the canvas pixels of a group of four rows are fetched a group ahead of their read-modify-write, by every lane (a load
+    // under a lane condition is waited for where the condition ends)
+    gu8 crow0 = nullptr;
+    long long cstep = 0;
+    f32x4_t cv[4] = {};
+    if (PASTE) {
+        crow0 = (gu8)reinterpret_cast<uint8_t*>(pp->canvas) + (long long)(y0 - pp->slab_y0) * pp->cstride + 16ll * xc;
+        cstep = pp->cstride;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<DR3_G f32x4_t*>(crow0 + (long long)min(u, n_rows - 1) * cstep);
+        pr = pp->ramp[xc - pp->min_x];
+        __builtin_amdgcn_sched_barrier(0);                       // ahead of the source box's loads
+    }
     if (r_any) {
         if (g.ox >= 0 && g.ox + 4 * g.cpr <= sw && g.oy >= 0 && g.oy + g.rows <= sh) stage_strip_bgrx<false>(g, src, sw, sh, sstride, lds0, lane);
         else                                                                          stage_strip_bgrx<true>(g, src, sw, sh, sstride, lds0, lane);
@@ -823,11 +901,18 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
         uint32_t nearest = 0xffffffffu;
         int aX[4], aY[4];
         uint32_t P[4] = {0u, 0u, 0u, 0u};
+        float po[4][3] = {};
         u32x3 ln[4] = {};
         if (STITCH && lmode == 1 && j0 + 4 < n_rows) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) ln[u] = left_row_load(lrow + (long long)min(j0 + 5 + u, n_rows) * slp->sstride);
             __builtin_amdgcn_sched_barrier(0);           // the scheduler would sink the loads to their uses, a group later
+        }
+        f32x4_t cn[4] = {};
+        if (PASTE && j0 + 4 < n_rows) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cn[u] = *reinterpret_cast<DR3_G f32x4_t*>(crow0 + (long long)min(j0 + 4 + u, n_rows - 1) * cstep);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (r_any) {
 #pragma unroll
@@ -841,6 +926,10 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
             const lds_u32 pt = (lds_u32)(uintptr_t)addr, pb = (lds_u32)(uintptr_t)(addr + pitch);
             const uint32_t tl = pt[0], tr = pt[1], bl = pb[0], br = pb[1];
             nearest = min(nearest, min((uint32_t)aX[u] & k8191, (uint32_t)aY[u] & k8191));
+            if (PASTE) {
+                paste_px_bgrx(tl, tr, bl, br, (int)__builtin_amdgcn_ubfe((uint32_t)aX[u], 13, 5), (int)__builtin_amdgcn_ubfe((uint32_t)aY[u], 13, 5), pr, po[u]);
+                continue;
+            }
             Blend8 w;
             w.wlo = __umul24(__builtin_amdgcn_ubfe((uint32_t)aX[u], 13, 5), 255u) + 32u;
             w.whi = __umul24(w.wlo, k64k);
@@ -884,6 +973,23 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
                 n_list += __builtin_popcountll(m);
             }
         }
+        if (PASTE) {
+            // written back by the lanes whose pixel is inside the box, off a rounding tie (those are pasted once, below) and not
+            // "empty" (:205-207)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < n_rows) {
+                    const bool tie = min((uint32_t)aX[u] & 8191u, (uint32_t)aY[u] & 8191u) < g2;
+                    if (x < dw && !tie && !(po[u][0] == 0.f && po[u][1] == 0.f && po[u][2] == 0.f)) {
+                        f32x4_t v = cv[u];
+                        v.x += po[u][0]; v.y += po[u][1]; v.z += po[u][2]; v.w += pr;
+                        *reinterpret_cast<DR3_G f32x4_t*>(crow0 + (long long)(j0 + u) * cstep) = v;
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = cn[u];
+            continue;
+        }
         uint32_t out[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)                                          // row_shl:1: the pixel of lane + 1
@@ -908,6 +1014,7 @@ __device__ __forceinline__ void strip_tile_body(const WarpJobDev& jb, const Warp
         if (i < n_list) { const uint32_t e = *(lds_u32)(uintptr_t)(list0 + 4u * (uint32_t)i); xe = tx0 + (int)(e & 255u); ye = y0 + (int)(e >> 8); i += 64; }
         else if (own) { xe = x; ye = y0 + __builtin_ctz(own); own &= own - 1u; }
         else break;
+        if (PASTE) { paste_px_checked(src, sw, sh, sstride, tile_redo_tap(M, bw0_shift, xe, ye), *pp, xe, ye); continue; }
         uint32_t v = tile_redo_pixel(M, bw0_shift, g, lds0, src, sw, sh, sstride, xe, ye);
         if (STITCH) {
             uint32_t Lp = 0u;
@@ -949,7 +1056,7 @@ __global__ __launch_bounds__(256) void warp_tile_8uc3_kernel(const WarpJobDev* _
     const WarpJobDev& jb = jobs[job];
     if (t >= n_tiles) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    strip_tile_body<false>(jb, nullptr, nullptr, t, tiles_x, lds_bytes, s_dyn, wv, wv);
+    strip_tile_body<0>(jb, nullptr, nullptr, nullptr, t, tiles_x, lds_bytes, s_dyn, wv, wv);
 }
 
 // the fused stitch on strips: a.job[1] (right image) through the strip machinery, a.job[0] (left image) in its translation form sl
@@ -965,7 +1072,18 @@ __global__ __launch_bounds__(64) void stitch_strip_kernel(const StitchDev sd, in
     const int bq = blockIdx.x, wv = (bq >> 3) & 3, b = (bq & 7) + 8 * (bq >> 5), r = b & (8 * run - 1);
     const int t = (b - r) + (r & 7) * run + (r / 8);
     if (t >= n_tiles) return;
-    strip_tile_body<true>(sd.a.job[1], &sd.a.job[0], &sd.sl, t, tiles_x, lds_bytes, s_dyn, wv, 0);
+    strip_tile_body<1>(sd.a.job[1], &sd.a.job[0], &sd.sl, nullptr, t, tiles_x, lds_bytes, s_dyn, wv, 0);
+}
+
+// the fused paste on strips: one wave per workgroup like the stitch (strips outside the image cost nothing, the others differ)
+struct PasteDev { WarpJobDev jb; PasteStrip ps; };
+__global__ __launch_bounds__(64) void paste_strip_kernel(const PasteDev pd, int tiles_x, int n_tiles, int lds_bytes, int run)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const int bq = blockIdx.x, wv = (bq >> 3) & 3, b = (bq & 7) + 8 * (bq >> 5), r = b & (8 * run - 1);
+    const int t = (b - r) + (r & 7) * run + (r / 8);
+    if (t >= n_tiles) return;
+    strip_tile_body<2>(pd.jb, nullptr, nullptr, &pd.ps, t, tiles_x, lds_bytes, s_dyn, wv, 0);
 }
 
 // MAPS = 0: (u, v) read from two f32 planes (cv::remap, reference src/utils.cpp:191).
@@ -1408,9 +1526,38 @@ hipError_t launch_stitch_compose(const StitchArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// May the paste run on strips?  The plan of the box (PanoAddArgs::tile / tile_lds / tile_guard, made by the host over the box's
+// pixels) says so; the strips start at the box's first column and row.
+bool paste_takes_strips(const PanoAddArgs& a)
+{
+#ifdef DR3_PASTE_NO_STRIPS
+    return false;
+#endif
+    return a.tile == 2 && a.tile_lds > 0 && a.fast == 3 && a.bw0_shift >= 0 && ((std::max(a.tile_lds, 1024) + 255) & ~255) <= kWarpTileLdsBytes;
+}
+
 hipError_t launch_panorama_add(const PanoAddArgs& a, hipStream_t s)
 {
     if (a.cx1 <= a.cx0 || a.cy1 <= a.cy0) return hipSuccess;
+    if (paste_takes_strips(a)) {
+        PasteDev pd;
+        WarpJobDev& j = pd.jb;
+        j.src = a.img; j.sw = a.w; j.sh = a.h; j.sstride = a.istride;
+        j.dst = nullptr; j.dw = a.cx1; j.dh = a.cy1; j.dstride = 0;          // the strips end at the box's last column / row
+        for (int i = 0; i < 9; ++i) j.M[i] = a.M[i];
+        j.bw0 = a.bw0; j.bw0_shift = a.bw0_shift; j.fast = a.fast; j.tile = 2; j.tile_lds = a.tile_lds; j.tile_guard = a.tile_guard;
+        pd.ps.canvas = a.canvas; pd.ps.cstride = a.cstride; pd.ps.slab_y0 = a.slab_y0; pd.ps.ramp = a.ramp; pd.ps.min_x = a.min_x;
+        pd.ps.x0 = a.cx0; pd.ps.y0 = a.cy0;
+        const int lds = (std::max(a.tile_lds, 1024) + 255) & ~255;
+        const int tiles_x = (a.cx1 - a.cx0 + kTileW - 1) / kTileW;
+        const long long n_tiles = (long long)tiles_x * ((a.cy1 - a.cy0 + kTileH - 1) / kTileH);
+        if (n_tiles < (1LL << 28)) {
+            const int run = tiles_x >= 32 ? 4 : 1, grp = 8 * run;
+            dim3 tgrid((unsigned)((n_tiles + grp - 1) / grp * grp * 4), 1, 1);
+            hipLaunchKernelGGL(paste_strip_kernel, tgrid, dim3(64, 1), lds + 256, s, pd, tiles_x, (int)n_tiles, lds, run);
+            return hipGetLastError();
+        }
+    }
     dim3 block(64, 4);
     const int tw = 1 << DR3_PANO_LOG, th = 4 * (64 >> DR3_PANO_LOG);
     dim3 grid((a.cx1 - a.cx0 + tw - 1) / tw, (a.cy1 - a.cy0 + th - 1) / th, 1);

@@ -1582,7 +1582,9 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
     d_img = ctx.to_device(tile)
     d_canvas = ctx.alloc(cw * ch * 16)
     d_out = ctx.alloc(cw * ch * 3)
-    box_px = sum((min(b[2], cw) - max(b[0], 0)) * ch for b in boxes)
+    plans = [dr3.panorama_plan(TW_, TH_, (cw, ch), M, istride=TW_ * 3) for M in Ms]      # (kernel, coordinate form, box) per paste
+    box_px = sum((p[2][2] - p[2][0]) * (p[2][3] - p[2][1]) for p in plans)                # canvas pixels the eight launches evaluate
+    add_kernel = "paste_strip_kernel" if all(p[0] == 2 for p in plans) else "panorama_add_kernel"
 
     def step():
         d_canvas.zero()
@@ -1624,9 +1626,13 @@ def paste_leg(dist, ctx, dr3, synth, sync, tile, steps):
             "tile_mpix_per_s": aggregate_rate(dist, 8 * TW_ * TH_ * steps / 1e6, el),
             "step_ms": el / steps * 1e3,
             "add_kernel_ms": add_ms, "box_pixels_per_step": box_px,
-            "roofline_add": {"kernel": "panorama_add_kernel", "bound": "hbm", "achieved": alg_add / (add_ms * 1e-3) / 1e9,
+            "kernel_plan": {"strips": sum(1 for p in plans if p[0] == 2), "direct": sum(1 for p in plans if p[0] != 2),
+                            "coordinate_forms": sorted(set(p[1] for p in plans)),
+                            "note": "dr3hip_panorama_plan per paste: strips = paste_strip_kernel (the image's box through the LDS-staged strip "
+                                    "machinery), direct = panorama_add_kernel; the plan is made over the box, not the whole canvas"},
+            "roofline_add": {"kernel": add_kernel, "bound": "hbm", "achieved": alg_add / (add_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_add / (add_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": pmc_traffic("panorama_add_kernel", 256, "pmc_traffic_warp.json")[0],
+                             "traffic": pmc_traffic(add_kernel, 256, "pmc_traffic_warp.json")[0],
                              "algorithmic_bytes_per_launch": alg_add},
             "roofline_normalize": {"kernel": "panorama_normalize_kernel", "bound": "hbm", "achieved": alg_norm / (norm_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_norm / (norm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DR3HIP_VERSION 103
+#define DR3HIP_VERSION 104
 #define DR3HIP_BATCH_MAX_W 4000000   /* widest frame of a dr3hip_batch: the tracker addresses rows of 4 (w + 2 pad) + 16 bytes with 24-bit pitches */
 
 /* error codes */
@@ -399,6 +399,13 @@ int dr3hip_panorama_add(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int
 int dr3hip_panorama_add_slab(dr3hip_ctx* ctx, const uint8_t* d_img, int w, int h, int istride,
                              float* d_canvas, int cw, int ch, int cstride,
                              const float M[9], int feathering_width, int slab_y0, int slab_y1);
+/* Which form dr3hip_panorama_add(_slab) runs for this image, canvas and matrix, without running it: *kernel = 2 the strip form (the
+ * image's box through the LDS-staged strip machinery of DESIGN.md 4.3.1), 0 the direct form (any matrix, any alignment); *coords = the
+ * coordinate form over the box (0 OpenCV's own f64 sequence per pixel ... 3 one anchor per strip column); box = the canvas columns and
+ * rows the launch evaluates {x0, y0, x1, y1}.  The pointer and stride as they would be passed (only their alignment matters); any of
+ * the three outputs may be NULL.  Host only. */
+int dr3hip_panorama_plan(const uint8_t* d_img, int w, int h, int istride, int cw, int ch, const float M[9], int slab_y0, int slab_y1,
+                         int* kernel, int* coords, int box[4]);
 /* Panorama::normalize_canvas (src/panorama.cpp:215-229): 32FC4 weighted canvas -> 8UC3 panorama. */
 int dr3hip_panorama_normalize(dr3hip_ctx* ctx, const float* d_canvas, int cw, int ch, int cstride,
                               uint8_t* d_out, int ostride);

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(dr3):
     out = subprocess.check_output(["nm", "-D", "--defined-only", dr3.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (dr3hip_[a-z0-9_]+)", out))
     assert set(declared) <= exported
-    assert L.dr3hip_version() == 103
+    assert L.dr3hip_version() == 104
 
 
 def test_no_cpu_fallback(dr3):

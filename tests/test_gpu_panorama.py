@@ -124,3 +124,75 @@ def test_canvas_slabs_of_several_gpus_equal_the_whole_canvas(dr3, O, ctx, synth)
         got[y0:y1] = d_slab.download((y1 - y0, cw, 4), np.float32)
         d_slab.free()
     assert np.array_equal(_bits(got), _bits(want)) and got[..., 3].max() >= 1.0
+
+
+def _paste_dev(ctx, img, M, canvas_size, fw, pad=0):
+    """one paste through the device entry point with an explicit row pitch (pad bytes beyond 3 w): -> canvas (H, W, 4) f32"""
+    cw, ch = canvas_size
+    h, w = img.shape[:2]
+    pitch = 3 * w + pad
+    host = np.zeros((h, pitch), np.uint8); host[:, :3 * w] = img.reshape(h, 3 * w)
+    d_img, d_c = ctx.to_device(host), ctx.alloc(cw * ch * 16)
+    try:
+        d_c.zero()
+        ctx.panorama_add(d_img, w, h, pitch, d_c, cw, ch, cw * 16, M, fw)
+        ctx.sync()
+        return d_c.download((ch, cw, 4), np.float32)
+    finally:
+        d_img.free(); d_c.free()
+
+
+@pytest.mark.parametrize("w,h", [(400, 300), (336, 210)])
+def test_strip_form_and_direct_form_paste_the_same_canvas(dr3, O, ctx, synth, w, h):
+    """16-byte aligned image rows and a nearly affine map take the strip form (paste_strip_kernel: the box of the image through the
+    LDS-staged strips of the 8UC3 warp), anything else the direct one (panorama_add_kernel); both equal the oracle bit for bit --
+    several tiles, box edges off the 64 x 16 grid, a perspective row, boxes cut by every canvas edge"""
+    rng = np.random.default_rng(w)
+    img = synth.panorama_tile(w, h, seed=0x3D52 + w)
+    img[h // 3: h // 3 + 9, w // 4: w // 4 + 40] = 0                          # exactly black pixels carry no weight (:205-207)
+    cases = []
+    for k in range(5):
+        a = rng.uniform(-0.05, 0.05)
+        cases.append(np.array([[np.cos(a), -np.sin(a), 37.3 + 11 * k], [np.sin(a), np.cos(a), 21.7 + 5 * k],
+                               [rng.uniform(-3e-5, 3e-5), rng.uniform(-3e-5, 3e-5), 1]], np.float32))
+    cases += [np.array([[1, 0, -150.25], [0, 1, -70.5], [1e-5, 0, 1]], np.float32),          # cut by the left and top edges
+              np.array([[1, 0, w * 0.8], [0, 1, h * 0.7], [0, 1e-5, 1]], np.float32)]         # ... by the right and bottom ones
+    size = (w + 180, h + 130)
+    assert (3 * w) % 16 == 0
+    took = set()
+    for M in cases:
+        want = np.zeros((size[1], size[0], 4), np.float32)
+        O.panorama_add(img, want, M, 40)
+        k_strip, coords, box = dr3.panorama_plan(w, h, size, M, istride=3 * w)
+        k_direct, _, _ = dr3.panorama_plan(w, h, size, M, istride=3 * w + 4)
+        assert k_direct == 0 and 0 <= box[0] < box[2] <= size[0] and 0 <= box[1] < box[3] <= size[1]
+        took.add(k_strip)
+        assert np.array_equal(_bits(_paste_dev(ctx, img, M, size, 40)), _bits(want)), ("strips" if k_strip == 2 else "direct", M)
+        assert np.array_equal(_bits(_paste_dev(ctx, img, M, size, 40, pad=4)), _bits(want)), ("direct", M)
+    assert 2 in took                                                           # the strip form did run
+
+
+def test_strip_paste_on_rounding_ties(dr3, O, ctx, synth):
+    """a translation by an odd multiple of 1/64 px puts EVERY pixel on a rounding tie of the 1/32-px grid: the strip form pastes such
+    pixels once, by OpenCV's own sequence, from its tie list (60 entries per strip) and, beyond it, from each lane's own bit mask"""
+    img = synth.panorama_tile(208, 96, seed=7)
+    for tx, ty in ((10.015625, 5.015625), (33.484375, 2.25), (7.5, 9.046875)):
+        M = np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float32)
+        want = np.zeros((140, 280, 4), np.float32)
+        O.panorama_add(img, want, M, 30)
+        assert dr3.panorama_plan(208, 96, (280, 140), M, istride=624)[0] == 2
+        assert np.array_equal(_bits(_paste_dev(ctx, img, M, (280, 140), 30)), _bits(want)), (tx, ty)
+
+
+def test_paste_of_a_tile_onto_a_canvas_wider_than_the_fast_coordinate_range(dr3, O, ctx, synth):
+    """the canvas of a panorama is wider than the +-8000 source pixels the fast coordinate forms cover; the plan is made over the
+    image's box, so the tile far right on a 12 000-px canvas still takes the strips (and the rows outside its box are not walked)"""
+    w, h = 320, 200
+    img = synth.panorama_tile(w, h, seed=11)
+    M = np.array([[0.9995, -0.03, 11500.4], [0.03, 0.9995, 40.2], [2e-6, 1e-6, 1]], np.float32)
+    size = (12000, 330)
+    k, coords, box = dr3.panorama_plan(w, h, size, M, istride=3 * w)
+    assert k == 2 and coords == 3 and box[0] > 11000 and box[3] - box[1] < 330
+    want = np.zeros((size[1], size[0], 4), np.float32)
+    O.panorama_add(img, want, M, 25)
+    assert np.array_equal(_bits(_paste_dev(ctx, img, M, size, 25)), _bits(want))

@@ -110,8 +110,11 @@ for case in range(n_cases):
             want[...] = rng.random((ch, cw, 4), dtype=f32) * (rng.random() < 0.5)
             start = want.copy()
             O.panorama_add(c3, want, Mp, fw)
-            d_c = ctx.to_device(start); d_i = ctx.to_device(c3); d_o = ctx.alloc(cw * ch * 3)
-            ctx.panorama_add(d_i, w, h, 3 * w, d_c, cw, ch, cw * 16, Mp, fw)
+            # image rows at a 16-byte aligned pitch in two cases of three (the strip form's condition), packed otherwise (the direct form)
+            pitch = (3 * w + 15) // 16 * 16 if case % 3 else 3 * w
+            host = np.zeros((h, pitch), np.uint8); host[:, :3 * w] = c3.reshape(h, 3 * w)
+            d_c = ctx.to_device(start); d_i = ctx.to_device(host); d_o = ctx.alloc(cw * ch * 3)
+            ctx.panorama_add(d_i, w, h, pitch, d_c, cw, ch, cw * 16, Mp, fw)
             ctx.panorama_normalize(d_c, cw, ch, cw * 16, d_o, cw * 3)
             gc_ = d_c.download((ch, cw, 4), f32); gp_ = d_o.download((ch, cw, 3), np.uint8)
             d_c.free(); d_i.free(); d_o.free()
