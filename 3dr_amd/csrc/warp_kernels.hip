@@ -1337,6 +1337,46 @@ __device__ __forceinline__ uint32_t half_px(int a, int b, int c, int d, int mode
     return (uint32_t)((a + b + c + d) >> 2);              // (a+b+c+d)/4, all non-negative
 }
 
+// The streaming form (rows 16-byte aligned, the truncating or the SSE2 rounding, 512 output pixels or more per row): a wave owns 1024
+// output pixels of one row; lane i reads bytes 16 i .. 16 i + 15 of the first KiB of both source rows and the same of the second KiB
+// (four fully coalesced 1-KiB loads, read once: non-temporal), averages in 16-bit halves of a dword -- even and odd bytes of a row are
+// the left and right pixels of two output pixels -- and stores 8 output bytes per segment (two coalesced 512-byte stores).
+__device__ __forceinline__ uint32_t half_pairs(uint32_t t, uint32_t b, int mode)      // bytes [p0 p1 p2 p3] of two rows -> 16-bit halves [o0, o1]
+{
+    const uint32_t m = 0x00ff00ffu, te = t & m, to = (t >> 8) & m, be = b & m, bo = (b >> 8) & m;
+    if (mode == DR3HIP_HALF_SSE2) {                       // _mm_avg_epu8 of the rows, then _mm_avg_epu16 of the even and odd bytes
+        const uint32_t ve = ((te + be + 0x00010001u) >> 1) & m, vo = ((to + bo + 0x00010001u) >> 1) & m;
+        return ((ve + vo + 0x00010001u) >> 1) & m;
+    }
+    return ((te + to + be + bo) >> 2) & m;                // (a + b + c + d) / 4
+}
+#ifndef DR3_HALF_SEGS
+#define DR3_HALF_SEGS 2
+#endif
+__global__ __launch_bounds__(256) void halfsample_wide_kernel(const HalfArgs a)
+{
+    const int lane = threadIdx.x;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    if (Y >= a.oh) return;
+    gcu8 src = (gcu8)(a.src + (long long)blockIdx.z * a.sstep + (long long)(2 * Y) * a.sstride);
+    gu8 drow = (gu8)(a.dst + (long long)blockIdx.z * a.dstep + (long long)Y * a.dstride);
+#pragma unroll
+    for (int seg = 0; seg < DR3_HALF_SEGS; ++seg) {
+        const int X = blockIdx.x * (512 * DR3_HALF_SEGS) + 512 * seg + 8 * lane;        // 8 output pixels
+        if (X >= a.ow) continue;
+        gcu8 r0 = src + 2 * X, r1 = r0 + a.sstride;
+        if (X + 8 <= a.ow) {
+            const u32x4 t = ld_once(gcast<u32x4>(r0)), b = ld_once(gcast<u32x4>(r1));
+            const uint32_t h0 = half_pairs(t.x, b.x, a.mode), h1 = half_pairs(t.y, b.y, a.mode), h2 = half_pairs(t.z, b.z, a.mode), h3 = half_pairs(t.w, b.w, a.mode);
+            u32x2 o;
+            o.x = __builtin_amdgcn_perm(h1, h0, 0x06040200u); o.y = __builtin_amdgcn_perm(h3, h2, 0x06040200u);
+            st_out(gcast<u32x2>(drow + X), o);
+        } else {
+            for (int k = 0; X + k < a.ow; ++k) drow[X + k] = (uint8_t)half_px(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1], a.mode);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void halfsample_kernel(const HalfArgs a)
 {
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;    // 4 output pixels per lane
@@ -1579,6 +1619,14 @@ hipError_t launch_halfsample(const HalfArgs& a, hipStream_t s)
 {
     if (a.ow <= 0 || a.oh <= 0) return hipSuccess;
     dim3 block(64, 4);
+#ifndef DR3_HALF_NO_WIDE
+    if (a.mode != DR3HIP_HALF_REF_SCALAR && a.ow >= 512 && (((uintptr_t)a.src | (uintptr_t)a.sstride | (uintptr_t)a.sstep) & 15) == 0 &&
+        (((uintptr_t)a.dst | (uintptr_t)a.dstride | (uintptr_t)a.dstep) & 7) == 0) {
+        dim3 wgrid((a.ow + 512 * DR3_HALF_SEGS - 1) / (512 * DR3_HALF_SEGS), (a.oh + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
+        hipLaunchKernelGGL(halfsample_wide_kernel, wgrid, block, 0, s, a);
+        return hipGetLastError();
+    }
+#endif
     dim3 grid((a.ow + 255) / 256, (a.oh + 3) / 4, a.n_slots > 0 ? a.n_slots : 1);
     hipLaunchKernelGGL(halfsample_kernel, grid, block, 0, s, a);
     return hipGetLastError();

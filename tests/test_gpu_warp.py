@@ -308,3 +308,26 @@ def test_strip_kernel_every_pixel_on_a_tie(dr3, O, ctx):
     M = np.array([[1, 1 / 32, 1 / 64], [0, 1, 0.25], [0, 0, 1]], np.float32)            # X moves by 1/32 px per row: a tie on every row
     got, plan = _warp_dev(dr3, ctx, src, M, (200, 100))
     assert plan["kernel"] == 2 and np.array_equal(got, O.warp_perspective(src, M, (200, 100)))
+
+
+@pytest.mark.parametrize("w,h,spitch,dpitch", [(2064, 37, 2064, 1032), (4100, 9, 4112, 2056), (1026, 5, 1040, 520), (3000, 6, 3008, 1500)])
+@pytest.mark.parametrize("mode", ["HALF_TRUNC", "HALF_SSE2"])
+def test_halfsample_streaming_form_equals_the_plain_one(dr3, O, ctx, w, h, spitch, dpitch, mode):
+    """rows at a 16-byte aligned pitch and 512 or more output pixels take halfsample_wide_kernel (1024 output pixels per wave, 16-byte
+    loads); the same image at an odd pitch takes the plain kernel: both equal the oracle -- row tails inside a segment, between the two
+    segments of a lane and between workgroups"""
+    rng = np.random.default_rng(w)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[:, ::7] = 255; img[1::2, 3::5] = 0                       # rounding ties of both averages
+    want = O.halfsample(img, getattr(O, mode))
+    for sp, dp in ((spitch, dpitch), (spitch + 3, dpitch + 1)):
+        host = np.zeros((h, sp), np.uint8); host[:, :w] = img
+        d_src, d_dst = ctx.to_device(host), ctx.alloc(dp * (h // 2))
+        try:
+            d_dst.zero()
+            ctx._chk(dr3.lib().dr3hip_halfsample_dev(ctx.h, d_src.ptr, w, h, sp, d_dst.ptr, dp, int(getattr(dr3, mode))))
+            got = d_dst.download((h // 2, dp), np.uint8)
+        finally:
+            d_src.free(); d_dst.free()
+        assert np.array_equal(got[:, :w // 2], want), (sp, dp)
+        assert not got[:, w // 2:].any()                          # nothing written behind a row's last pixel
