@@ -1422,7 +1422,9 @@ def halfsample_leg(dist, ctx, dr3, sync, tile, steps):
         a_.free(); b_.free()
     ach = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {"image": [w, h], "kernel_ms": k_ms, "verified_vs_oracle": ok, "buffer_sets_rotated": n_sets,
-            "roofline": {"kernel": "halfsample_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # 16-byte aligned rows, the SSE2 arithmetic (REF_X86 at a width that is a multiple of 16) and >= 512 output pixels per row:
+            # the streaming form (launch_halfsample in warp_kernels.hip)
+            "roofline": {"kernel": "halfsample_wide_kernel" if (w % 16 == 0 and w // 2 >= 512) else "halfsample_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": nbytes}}
 
 
