@@ -32,6 +32,7 @@ struct dr3hip_ctx {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf stage[9];          // [7] is the bounce buffer of copy2d_h2d / copy2d_d2h, [8] the sparse alignment's patch cache
     dr3hip_batch* lk_batch = nullptr;     // cached 2-slot batch behind dr3hip_lk_track
+    void* pin_io = nullptr; size_t pin_io_cap = 0;      // pinned host buffer of dr3hip_lk_track: points in, results out, one copy each way
     bool prof = false;
     double prof_ms[DR3HIP_PROF_SLOTS] = {0};
     int prof_n[DR3HIP_PROF_SLOTS] = {0};
@@ -293,6 +294,7 @@ void dr3hip_destroy(dr3hip_ctx* ctx)
     if (ctx->lk_batch) dr3hip_batch_destroy(ctx->lk_batch);
     (void)dr3hip_comm_destroy(ctx);
     for (auto& b : ctx->stage) if (b.p) (void)hipFree(b.p);
+    if (ctx->pin_io) (void)hipHostFree(ctx->pin_io);
     xfer_release(ctx);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -1586,27 +1588,55 @@ int dr3hip_lk_track(dr3hip_ctx* ctx, const uint8_t* prev, const uint8_t* next, i
         if (rc != DR3HIP_OK) return rc;
         ctx->lk_batch = b;
     }
+    // One call of the reference (src/initialization.cpp:608) is one frame pair: what it costs here is launches, copies and host waits, not
+    // arithmetic.  Both frames cross PCIe into one bounce buffer and get their borders in ONE launch, both pyramids are ONE pass of four
+    // launches (the second frame's derivatives ride along: one frame of them is cheaper than a launch), the points go in and the
+    // results come out as ONE copy each through a pinned buffer, and the host waits once, at the end.
     int rc;
-    if ((rc = dr3hip_batch_upload(b, 0, 1, prev, prev_stride, 0)) != DR3HIP_OK) return rc;
-    if ((rc = dr3hip_batch_upload(b, 1, 1, next, next_stride, 0)) != DR3HIP_OK) return rc;
-    if ((rc = dr3hip_batch_build(b, 0, 1, 1)) != DR3HIP_OK) return rc;
-    if ((rc = dr3hip_batch_build(b, 1, 1, 0)) != DR3HIP_OK) return rc;
+    const LevelDev& v = b->lv[0];
+    const size_t fb0 = (size_t)prev_stride * (h - 1) + w, fb1 = (size_t)next_stride * (h - 1) + w;
+    const size_t fstep = (size_t)align_up((long long)(fb0 > fb1 ? fb0 : fb1) + 64, 256ll);
+    if ((rc = stage_reserve(ctx, 7, 2 * fstep))) return rc;
+    uint8_t* bounce = (uint8_t*)ctx->stage[7].p;
+    HIPCHK(ctx, hipMemcpyAsync(bounce, prev, fb0, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(bounce + fstep, next, fb1, hipMemcpyHostToDevice, ctx->stream));
+    const int fill = align_up(b->win_w + 16, 4);
+    if (prev_stride == next_stride) {
+        HIPCHK(ctx, launch_upload_level0(bounce, (size_t)prev_stride, v, 0, fill, ctx->stream, 2, fstep));
+    } else {
+        HIPCHK(ctx, launch_upload_level0(bounce, (size_t)prev_stride, v, 0, fill, ctx->stream, 1, 0));
+        HIPCHK(ctx, launch_upload_level0(bounce + fstep, (size_t)next_stride, v, 1, fill, ctx->stream, 1, 0));
+    }
+    if ((rc = dr3hip_batch_build(b, 0, 2, 1)) != DR3HIP_OK) return rc;
     if (n == 0) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return L; }
 
-    const size_t xyb = (size_t)n * 2 * sizeof(float);
-    if ((rc = stage_reserve(ctx, 0, xyb)) || (rc = stage_reserve(ctx, 1, xyb)) ||
-        (rc = stage_reserve(ctx, 2, (size_t)n)) || (rc = stage_reserve(ctx, 3, (size_t)n * sizeof(float)))) return rc;
-    float* d_prev = (float*)ctx->stage[0].p; float* d_next = (float*)ctx->stage[1].p;
-    uint8_t* d_status = (uint8_t*)ctx->stage[2].p; float* d_err = (float*)ctx->stage[3].p;
-    HIPCHK(ctx, hipMemcpyAsync(d_prev, prev_xy, xyb, hipMemcpyHostToDevice, ctx->stream));
+    // device: [prev_xy 8 n][next_xy 8 n][err 4 n][status n]; the pinned buffer mirrors [prev_xy][next_xy] on the way in and
+    // [next_xy][err][status] on the way out
+    const size_t xyb = (size_t)n * 2 * sizeof(float), outb = xyb + (size_t)n * sizeof(float) + (size_t)n;
+    if ((rc = stage_reserve(ctx, 0, xyb + outb))) return rc;
+    if (ctx->pin_io_cap < 2 * xyb + outb) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pin_io) { (void)hipHostFree(ctx->pin_io); ctx->pin_io = nullptr; ctx->pin_io_cap = 0; }
+        const size_t cap = 2 * (2 * xyb + outb) + 4096;
+        if (hipHostMalloc(&ctx->pin_io, cap, hipHostMallocDefault) != hipSuccess) { ctx->pin_io = nullptr; return fail(ctx, DR3HIP_ENOMEM, "hipHostMalloc(%zu) failed", cap); }
+        ctx->pin_io_cap = cap;
+    }
+    float* d_prev = (float*)ctx->stage[0].p; float* d_next = d_prev + 2 * (size_t)n;
+    float* d_err = d_next + 2 * (size_t)n; uint8_t* d_status = (uint8_t*)(d_err + n);
+    uint8_t* pin = (uint8_t*)ctx->pin_io;
+    const bool seeded = (p->flags & DR3HIP_LK_USE_INITIAL_FLOW) != 0;
+    std::memcpy(pin, prev_xy, xyb);
     // without USE_INITIAL_FLOW OpenCV never reads nextPts; seed with prevPts so the upload is defined
-    HIPCHK(ctx, hipMemcpyAsync(d_next, (p->flags & DR3HIP_LK_USE_INITIAL_FLOW) ? next_xy : prev_xy, xyb, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(pin + xyb, seeded ? next_xy : prev_xy, xyb);
+    HIPCHK(ctx, hipMemcpyAsync(d_prev, pin, 2 * xyb, hipMemcpyHostToDevice, ctx->stream));
     rc = dr3hip_batch_track(b, 1, 0, nullptr, nullptr, d_prev, d_next, n, d_status, d_err, nullptr, p);
     if (rc < 0) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(next_xy, d_next, xyb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(status, d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(err, d_err, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t* pout = pin + 2 * xyb;
+    HIPCHK(ctx, hipMemcpyAsync(pout, d_next, outb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(next_xy, pout, xyb);
+    std::memcpy(err, pout + xyb, (size_t)n * sizeof(float));
+    std::memcpy(status, pout + xyb + (size_t)n * sizeof(float), (size_t)n);
     return rc;
 }
 
