@@ -51,6 +51,14 @@
 #include "dr3hip_internal.h"
 #include "wave_tree.h"
 
+// This file is compiled TWICE (Makefile): LKG_TU = 0, the tracker's translation unit proper, and LKG_TU = 1, the launches of the forms
+// that hold eight points per wave (windows up to 16 x 16: the headline's 15 x 15), built with LLVM's max-ILP machine scheduler
+// (-mllvm -amdgpu-sched-strategy=max-ilp: 0.865 -> 0.82 ms per launch of the headline shape on the same box; the quarter-wave 21 x 21 form
+// loses 1.4 % under it and the warp kernels 3 - 13 %, so only these forms get it -- profiles/r04_lk/README.md section 9).
+#ifndef LKG_TU
+#define LKG_TU 0
+#endif
+
 namespace dr3 {
 namespace {
 
@@ -660,6 +668,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PPW == 8 ? (
 }
 
 
+#if LKG_TU == 0
 // ---- windows beyond 32 x 32 (up to DR3HIP_MAX_WIN = 64): the plain form ----------------------------------------------------------------
 // cv::calcOpticalFlowPyrLK has no window limit; the reference's own 30 x 30 and every BASELINE configuration run on the kernel above,
 // and this one only removes the limit: ONE wave per point, the same cut of the window into lane-items of 8 rows of a column
@@ -809,8 +818,10 @@ __global__ __launch_bounds__(64) void lk_track_big_kernel(const LKArgs a)
     }
 }
 
+#endif
 }  // namespace
 
+#if LKG_TU == 0
 // ---- counters over the tracker's outputs (dr3hip_lk_stats): per-wave ballots / LDS histogram, one atomic per counter and block -----
 namespace {
 __global__ __launch_bounds__(256) void lk_stats_kernel(long long n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ reason,
@@ -848,6 +859,19 @@ hipError_t launch_lk_stats(long long n, const uint8_t* status, const uint8_t* re
 
 // group shape by window (the CPU checker's summation-order rule is the same): points per wave ppw (64 / ppw lanes per point) and
 // lane-items per lane ni
+#endif
+
+#if LKG_TU == 1
+// the launches of the eight-points-per-wave forms (this translation unit is built with the max-ILP scheduler)
+hipError_t launch_lk_track_p8(const LKArgs& a, bool win15, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const LaunchEv* ev)
+{
+    if (win15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 8, 2>), grid, block, shmem, s, a);
+    else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 8, 2>), grid, block, shmem, s, a);
+    return hipGetLastError();
+}
+#else
+hipError_t launch_lk_track_p8(const LKArgs& a, bool win15, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const LaunchEv* ev);
+
 static inline void lk_group_shape(int win_w, int win_h, int& ppw, int& ni)
 {
     const int n8 = win_w * ((win_h + 7) / 8);
@@ -884,8 +908,7 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     const size_t shmem = ((size_t)ppw * rhs * lpd + (wide ? (size_t)ppw * irows * (cols + 1) : 0)) * sizeof(uint32_t);
     const int sq = a.win_w == a.win_h ? a.win_w : 0;
     if (ppw == 8) {
-        if (sq == 15) DR3_LAUNCH(ev, (lk_trackg_kernel<15, 8, 2>), grid, block, shmem, s, a);
-        else DR3_LAUNCH(ev, (lk_trackg_kernel<0, 8, 2>), grid, block, shmem, s, a);
+        return launch_lk_track_p8(a, sq == 15, grid, block, shmem, s, ev);           // the other translation unit (LKG_TU = 1)
     } else if (ppw == 4 && ni == 4) {
         DR3_LAUNCH(ev, (lk_trackg_kernel<21, 4, 4>), grid, block, shmem, s, a);
     } else if (ppw == 4) {
@@ -902,5 +925,7 @@ hipError_t launch_lk_track(const LKArgs& a, int n_pairs, hipStream_t s, const La
     }
     return hipGetLastError();
 }
+
+#endif
 
 }  // namespace dr3

@@ -37,12 +37,17 @@ def source_hash():
 
 
 def compile_isa():
+    """the ISA of both translation units lk_kernels.hip is built into (3dr_amd/csrc/Makefile): LKG_TU = 0 with the default flags, and
+    LKG_TU = 1 -- the eight-points-per-wave forms -- under the max-ILP machine scheduler"""
+    out_all = ""
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "lk.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                               "-fno-fast-math", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-                               "-o", out, SRC], stderr=subprocess.DEVNULL)
-        return open(out).read()
+        for tu, extra in ((0, []), (1, ["-DLKG_TU=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"])):
+            out = os.path.join(d, "lk%d.s" % tu)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                                   "-fno-fast-math", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + extra +
+                                  ["-S", "--cuda-device-only", "-o", out, SRC], stderr=subprocess.DEVNULL)
+            out_all += open(out).read()
+    return out_all
 
 
 def cost_of(line):
