@@ -62,3 +62,32 @@ def test_warp_and_stitch_plans(dr3):
     Hinv, T, Mr, size = dr3.stitch_geometry(H, 4000, 3000)
     assert dr3.stitch_plan(4000, 3000, 4000, 3000, T, Mr, size, lstride=12000, rstride=12000) == 2
     assert dr3.stitch_plan(4000, 3000, 4000, 3000, T, Mr, size, lstride=12004, rstride=12000) == 0
+
+
+def test_paste_plan_properties_over_random_homographies(dr3):
+    """the box a plan reports is the reference's bounding box (src/panorama.cpp:112-138) cut to the canvas, rows included in the canvas;
+    the strip form implies the anchored coordinate form and aligned rows; an unaligned pitch never changes the box or the coordinate form"""
+    rng = np.random.default_rng(2026)
+    seen = set()
+    for _ in range(300):
+        w, h = int(rng.integers(16, 900)) * 2, int(rng.integers(16, 700))
+        cw, ch = int(rng.integers(w // 2, 3 * w)), int(rng.integers(h // 2, 3 * h))
+        a = rng.uniform(-0.3, 0.3)
+        s_ = rng.uniform(0.6, 1.5)
+        M = np.array([[s_ * np.cos(a), -s_ * np.sin(a), rng.uniform(-0.5 * w, cw)], [s_ * np.sin(a), s_ * np.cos(a), rng.uniform(-0.5 * h, ch)],
+                      [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]], np.float32)
+        bb = dr3.panorama_bbox(M, w, h)
+        pitch = (3 * w + 15) // 16 * 16
+        try:
+            k, coords, box = dr3.panorama_plan(w, h, (cw, ch), M, istride=pitch)
+        except dr3.Dr3HipError:
+            assert bb[2] - bb[0] < 2 or bb[2] - bb[0] > (1 << 24)          # only what the reference throws on
+            continue
+        assert box[0] == max(bb[0], 0) and box[2] == min(bb[2], cw) and 0 <= box[1] and box[3] <= ch
+        assert k in (0, 2) and 0 <= coords <= 3
+        if k == 2:
+            assert coords == 3 and box[2] > box[0] and box[3] > box[1]
+        k2, c2, b2 = dr3.panorama_plan(w, h, (cw, ch), M, istride=pitch + 4)
+        assert k2 == 0 and c2 == coords and b2 == box
+        seen.add((k, coords))
+    assert (2, 3) in seen and any(k == 0 for k, _ in seen)
